@@ -1,0 +1,117 @@
+"""The oracle (CPU restatement) against the goldens produced by the REFERENCE itself
+(oracle/gen_goldens.py).  No GPU, no /root/reference at run time."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import iso226, pgd as opgd, projections as OP, wav2vec2 as OW
+from oracle.gen_cases import NORM_CASES, LENGTHS, AMPS, PGD_CASES, PGD_TEXTS, case_name, cli_to_args
+from paa_amd import arch as A, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_iso_tables(gold):
+    g = gold("iso.npz")
+    phons, freqs, w = iso226.weight_grid()
+    np.testing.assert_allclose(freqs, g["freqs"], rtol=0, atol=0)
+    np.testing.assert_allclose(phons, g["phons"], rtol=0, atol=0)
+    np.testing.assert_allclose(w, g["weights"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(iso226.interp_weights(g["probes"]), g["probe_vals"], rtol=1e-12, atol=1e-14)
+    for phon in (20, 25, 0, 90):
+        np.testing.assert_array_equal(iso226.phon_threshold(phon), g[f"spl_thresh_{phon}"].reshape(-1))
+
+
+def test_stft_istft(gold):
+    g = gold("projections.npz")
+    args = OP.default_args()
+    for L in (4096, 5000):
+        p = torch.from_numpy(np.concatenate([synth.perturbation(L) * np.float32(1e-2), synth.clean_audio(1, L)], 0))
+        S = OP.compute_stft(p, args)
+        ref = torch.view_as_complex(torch.from_numpy(g[f"stft|L{L}"]))
+        assert S.shape == ref.shape
+        assert (S - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+        y = OP.compute_istft(ref, args)
+        np.testing.assert_allclose(y.numpy(), g[f"istft|L{L}"], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("norm,extra", NORM_CASES)
+def test_projections(gold, norm, extra):
+    g = gold("projections.npz")
+    args = cli_to_args(norm, extra)
+    spl = OP.spl_thresh_tensor(args)
+    for L in LENGTHS + [16000]:
+        for B in ([1, 3] if norm in ("snr", "tv") else [1]):
+            for amp in AMPS:
+                clean = torch.from_numpy(synth.clean_audio(B, L))
+                p = torch.from_numpy(synth.perturbation(L) * np.float32(amp))
+                q = OP.perturbation_constraint(p, clean, args, spl).numpy()
+                name = case_name(norm, extra, L, B, amp)
+                if L == 16000:
+                    ref = g[name + "|samples"]
+                    got = q[0, ::7]
+                else:
+                    ref = g[name]
+                    got = q
+                scale = max(np.abs(ref).max(), 1e-30)
+                assert np.abs(got - ref).max() <= 5e-6 * scale, name
+
+
+def test_fm_norm_scalar(gold):
+    g = gold("projections.npz")
+    args = OP.default_args(norm_type="fletcher_munson")
+    for amp in AMPS:
+        S = OP.compute_stft(torch.from_numpy(synth.perturbation(4096) * np.float32(amp)), args)
+        assert float(OP.fm_weighted_norm(S, args)) == pytest.approx(float(g[f"fm_norm|L4096|a{amp:g}"][0]), rel=2e-6)
+
+
+def test_labels_and_decode():
+    with open(os.path.join(GOLD, "labels.json")) as f:
+        g = json.load(f)
+    for mode in ("untargeted", "targeted"):
+        args = OP.default_args(attack_mode=mode)
+        texts = g[mode]["texts"]
+        assert opgd.clean_transcripts(texts) == g[mode]["cleaned"]
+        lab = opgd.make_labels(texts, args, len(texts))
+        assert lab.tolist() == g[mode]["labels"]
+    ids = g["decode"]["ids"]
+    width = max(len(r) for r in ids)
+    onehot = torch.zeros(len(ids), width, 32)
+    for r, row in enumerate(ids):
+        for t in range(width):
+            onehot[r, t, row[t] if t < len(row) else 0] = 1.0
+    assert opgd.greedy_decode(onehot) == g["decode"]["texts"]
+
+
+@pytest.mark.parametrize("case", [c[0] for c in PGD_CASES])
+def test_pgd_step(gold, case):
+    name, a, L, B, norm, extra = next(c for c in PGD_CASES if c[0] == case)
+    g = gold(f"pgd_{name}.npz")
+    args = cli_to_args(norm, extra)
+    sd = OW.to_torch(A.rule_weights(a))
+    clean = torch.from_numpy(synth.clean_audio(B, L))
+    p0 = torch.from_numpy(synth.perturbation(L) * np.float32(1e-2))
+    texts = PGD_TEXTS[:B]
+    labels = opgd.make_labels(texts, args, B)
+    r = opgd.pgd_step(sd, a, args, clean, labels, p0, OP.spl_thresh_tensor(args))
+    assert float(r["loss"]) == pytest.approx(float(g["loss"][0]), rel=2e-5)
+    assert float(r["loss"]) == pytest.approx(float(g["avg_ctc"][0]), rel=2e-5)
+    if "grad" in g:
+        grad, gref = r["grad"].numpy(), g["grad"]
+        pn, pref = r["p_new"].numpy(), g["p_new"]
+        lg, lref = r["logits"].numpy(), g["logits"]
+    else:
+        grad, gref = r["grad"].numpy()[0, ::13], g["grad_samples"]
+        pn, pref = r["p_new"].numpy()[0, ::13], g["p_new_samples"]
+        lg, lref = r["logits"].numpy()[:, ::7, :], g["logits_samples"]
+    np.testing.assert_allclose(lg, lref, rtol=0, atol=5e-4 * np.abs(lref).max())
+    assert np.abs(grad - gref).max() <= 2e-3 * np.abs(gref).max()
+    # p' may differ only where the gradient sign is numerically undecided (SURVEY §7 'sign() sensitivity')
+    flips = np.sign(grad) != np.sign(gref)
+    assert flips.mean() < 2e-3
+    ok = ~flips.reshape(pn.shape) if flips.shape != pn.shape else ~flips
+    assert np.abs(pn - pref)[ok].max() <= 1e-5 * max(np.abs(pref).max(), 1e-30) + 1e-9
+    assert opgd.compute_wer(r["logits"], texts) == pytest.approx(float(g["avg_wer"][0]), abs=1e-12)
