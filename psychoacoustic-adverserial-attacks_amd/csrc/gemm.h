@@ -1,0 +1,55 @@
+// Descriptor of the one MFMA GEMM every conv / linear / attention product of the PGD step uses.
+//   C[z][m][n] = epilogue( sum_k A[z][m][k] * B[z][k][n] )        m < M, n < N, k < K, z < batch
+// Operands and result are f32 in HBM; operands are converted to bf16 (precision 0) or split into
+// bf16 hi + lo (precision 1, three MFMA passes: hi*hi + hi*lo + lo*hi) on their way into LDS, and
+// accumulated in f32 by v_mfma_f32_32x32x16_bf16.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PAA_ACT_NONE = 0, PAA_ACT_GELU = 1, PAA_ACT_GELU_GRAD = 2 };
+
+typedef struct paa_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    int32_t M, N, K;
+    // A element (m, k):  a_kcontig ? A[m * lda + koff(k)] : A[k * lda + m]
+    //   koff(k) = (k / a_kseg) * a_kseg_stride + k % a_kseg      (a_kseg = 0 means one segment: koff(k) = k)
+    //   a_window != 0 (pos-conv): segment js = k / a_kseg reads row (m + js - a_pad) of a clip of a_rows_valid
+    //   rows, zero outside [0, a_rows_valid):  A[(m + js - a_pad) * lda + k % a_kseg]
+    int64_t lda;
+    int32_t a_kcontig, a_kseg;
+    int64_t a_kseg_stride;
+    int32_t a_window, a_pad, a_rows_valid;
+    // B element (k, n):  b_kcontig ? B[n * ldb + k] : B[k * ldb + n]
+    int64_t ldb;
+    int32_t b_kcontig;
+    int64_t ldc;
+    // batch index z -> (z1, z2) = (z / batch2, z % batch2); operand offset = z1 * s1 + z2 * s2 (elements)
+    int32_t batch, batch2;
+    int64_t a_s1, a_s2, b_s1, b_s2, c_s1, c_s2;
+    // epilogue, in this order: v = acc * alpha; v += bias[z2 * bias_s2 + n];
+    //   act GELU: C_pre[m,n] = v (if C_pre), v = gelu(v);  act GELU_GRAD: v *= gelu'(aux[m,n]);
+    //   v += residual[m,n]; rows with (m % row_period) >= row_valid are forced to 0 (row_period > 0);
+    //   C = accumulate ? C + v : v
+    float alpha;
+    const float* bias;
+    int64_t bias_s2;
+    int32_t act;
+    float* C_pre;
+    const float* aux;
+    int64_t ld_aux, aux_s1, aux_s2;
+    const float* residual;
+    int64_t ld_res, res_s1, res_s2;
+    int32_t row_period, row_valid;
+    int32_t accumulate;
+    int32_t precision;   // 0 = bf16, 1 = split bf16 (fp32-parity)
+} paa_gemm_desc;
+
+#ifdef __cplusplus
+}
+#endif

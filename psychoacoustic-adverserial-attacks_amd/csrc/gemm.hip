@@ -1,0 +1,286 @@
+// MFMA GEMM for gfx950 (see gemm.h for the contract).
+//
+// Tile 128 x BN (BN = 128 | 64), BK = 32, 256 threads = 4 waves as 2 (M) x 2 (N); each wave owns a
+// 64 x BN/2 sub-tile = 2 x (BN/64) accumulators of v_mfma_f32_32x32x16_bf16 (16 f32 regs each).
+// Operands are f32 in HBM: a thread loads float4 vectors, converts to bf16 (and, in split mode, the
+// bf16 of the residual) and writes K-contiguous rows of 32 bf16 + 8 pad (80-byte row stride, which
+// makes the 16-byte fragment reads of all four ds_read_b128 lane groups conflict-free).  The next
+// tile's global loads are issued before the current tile's MFMAs, so HBM/L2 latency hides under them.
+// The loaders cover four operand shapes: K-contiguous rows with an arbitrary (even overlapping) row
+// stride — which is how the strided 1-D convolutions become plain GEMMs on a channel-last layout —
+// segmented K with a zero-filled time window (the grouped positional convolution), and the
+// M-/N-contiguous (transposed) operands of the attention backward products.
+#include <algorithm>
+
+#include "gemm.h"
+#include "paa_common.h"
+
+namespace paa {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int G_BM = 128, G_BK = 32, G_LD = 40 /* bf16 per LDS row */, G_NT = 256;
+
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+struct GemmArgs {
+    paa_gemm_desc d;
+    int tiles_m, tiles_n;
+};
+
+// ---- global -> register tile loads --------------------------------------------------------------
+// K-contiguous operand: ROWS x 32 tile, thread (r = tid>>3 [+32 i], kv = tid&7) loads float4 at k0 + 4 kv.
+template <int ROWS, bool IS_A>
+__device__ __forceinline__ void load_kc(const paa_gemm_desc& d, const float* __restrict__ base, int64_t ld, int r0,
+                                        int k0, int rlim, float4 (&v)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+    const int k = k0 + ((tid & 7) << 2);
+    int64_t koff = k;
+    int js = 0, kc = k;
+    if (IS_A && d.a_kseg > 0) {
+        js = k / d.a_kseg;
+        kc = k - js * d.a_kseg;
+        koff = (int64_t)js * d.a_kseg_stride + kc;
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int r = r0 + (tid >> 3) + 32 * i;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool ok = (r < rlim) && (k < d.K);
+        const float* p;
+        if (IS_A && d.a_window) {
+            const int tr = r + js - d.a_pad;
+            ok = ok && (tr >= 0) && (tr < d.a_rows_valid);
+            p = base + (int64_t)tr * ld + kc;
+        } else {
+            p = base + (int64_t)r * ld + koff;
+        }
+        if (ok) {
+            x = *reinterpret_cast<const float4*>(p);
+            if (k + 3 >= d.K) {                       // K tail: the vector may straddle K
+                if (k + 1 >= d.K) x.y = 0.f;
+                if (k + 2 >= d.K) x.z = 0.f;
+                x.w = 0.f;
+            }
+        }
+        v[i] = x;
+    }
+}
+
+// Row-contiguous ("transposed") operand: element (r, k) at base[k * ld + r]; tile 32 (k) x ROWS.
+template <int ROWS>
+__device__ __forceinline__ void load_rc(const paa_gemm_desc& d, const float* __restrict__ base, int64_t ld, int r0,
+                                        int k0, int rlim, float4 (&v)[ROWS / 32]) {
+    constexpr int VPK = ROWS / 4;          // float4 per k-row
+    constexpr int KSTEP = G_NT / VPK;      // k-rows per pass
+    const int tid = threadIdx.x;
+    const int r = r0 + ((tid % VPK) << 2);
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int k = k0 + tid / VPK + KSTEP * i;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < d.K && r < rlim) {
+            x = *reinterpret_cast<const float4*>(base + (int64_t)k * ld + r);
+            if (r + 3 >= rlim) {
+                if (r + 1 >= rlim) x.y = 0.f;
+                if (r + 2 >= rlim) x.z = 0.f;
+                x.w = 0.f;
+            }
+        }
+        v[i] = x;
+    }
+}
+
+// ---- register -> LDS (convert to bf16 hi [+ lo]) ------------------------------------------------
+template <int ROWS, int PREC>
+__device__ __forceinline__ void store_kc(unsigned short* hi, unsigned short* lo, const float4 (&v)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int off = ((tid >> 3) + 32 * i) * G_LD + ((tid & 7) << 2);
+        const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = bf16_bits(f[j]);
+            if (PREC) l[j] = bf16_bits(f[j] - bf16_to_f32(h[j]));
+        }
+        *reinterpret_cast<uint2*>(hi + off) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        if (PREC)
+            *reinterpret_cast<uint2*>(lo + off) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+}
+
+template <int ROWS, int PREC>
+__device__ __forceinline__ void store_rc(unsigned short* hi, unsigned short* lo, const float4 (&v)[ROWS / 32]) {
+    constexpr int VPK = ROWS / 4;
+    constexpr int KSTEP = G_NT / VPK;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int k = tid / VPK + KSTEP * i;
+        const int r = (tid % VPK) << 2;
+        const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned short h = bf16_bits(f[j]);
+            hi[(r + j) * G_LD + k] = h;
+            if (PREC) lo[(r + j) * G_LD + k] = bf16_bits(f[j] - bf16_to_f32(h));
+        }
+    }
+}
+
+template <int BN, int PREC, bool AKC, bool BKC>
+__global__ __launch_bounds__(G_NT) void k_gemm(GemmArgs g) {
+    constexpr int NPL = PREC ? 2 : 1;
+    constexpr int NJ = BN / 64;                          // 32-wide accumulator columns per wave
+    __shared__ __attribute__((aligned(16))) unsigned short smem[NPL * (G_BM + BN) * G_LD];
+    unsigned short* sAh = smem;
+    unsigned short* sAl = smem + (PREC ? G_BM * G_LD : 0);
+    unsigned short* sBh = smem + NPL * G_BM * G_LD;
+    unsigned short* sBl = sBh + (PREC ? BN * G_LD : 0);
+
+    const paa_gemm_desc& d = g.d;
+    // XCD-aware tile order: blocks that share (id % 8) — i.e. an XCD's L2 — get a contiguous run of tiles,
+    // and tiles that share an A row-panel are adjacent in that run (bijective for any tile count).
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int orig = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int m0 = tm * G_BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int z1 = z / d.batch2, z2 = z - z1 * d.batch2;
+    const float* A = d.A + z1 * d.a_s1 + z2 * d.a_s2;
+    const float* B = d.B + z1 * d.b_s1 + z2 * d.b_s2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[G_BM / 32], rb[BN / 32];
+    const int nk = (d.K + G_BK - 1) / G_BK;
+    if (AKC) load_kc<G_BM, true>(d, A, d.lda, m0, 0, d.M, ra); else load_rc<G_BM>(d, A, d.lda, m0, 0, d.M, ra);
+    if (BKC) load_kc<BN, false>(d, B, d.ldb, n0, 0, d.N, rb); else load_rc<BN>(d, B, d.ldb, n0, 0, d.N, rb);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (AKC) store_kc<G_BM, PREC>(sAh, sAl, ra); else store_rc<G_BM, PREC>(sAh, sAl, ra);
+        if (BKC) store_kc<BN, PREC>(sBh, sBl, rb); else store_rc<BN, PREC>(sBh, sBl, rb);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int k0 = (kt + 1) * G_BK;
+            if (AKC) load_kc<G_BM, true>(d, A, d.lda, m0, k0, d.M, ra); else load_rc<G_BM>(d, A, d.lda, m0, k0, d.M, ra);
+            if (BKC) load_kc<BN, false>(d, B, d.ldb, n0, k0, d.N, rb); else load_rc<BN>(d, B, d.ldb, n0, k0, d.N, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + lr) * G_LD + ks * 16 + lh * 8;
+                ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
+                if (PREC) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int off = (wn * (BN / 2) + j * 32 + lr) * G_LD + ks * 16 + lh * 8;
+                bh[j] = *reinterpret_cast<const bf16x8*>(sBh + off);
+                if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sBl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (PREC) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    float* C = d.C + z1 * d.c_s1 + z2 * d.c_s2;
+    float* Cp = d.C_pre ? d.C_pre + z1 * d.c_s1 + z2 * d.c_s2 : nullptr;
+    const float* aux = d.aux ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2 : nullptr;
+    const float* res = d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr;
+    const float* bias = d.bias ? d.bias + z2 * d.bias_s2 : nullptr;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + lr;
+        if (n >= d.N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                float v = acc[i][j][e] * d.alpha + bv;
+                if (d.act == PAA_ACT_GELU) {
+                    if (Cp) Cp[(int64_t)m * d.ldc + n] = v;
+                    v = gelu_f(v);
+                } else if (d.act == PAA_ACT_GELU_GRAD) {
+                    v *= gelu_grad_f(aux[(int64_t)m * d.ld_aux + n]);
+                }
+                if (res) v += res[(int64_t)m * d.ld_res + n];
+                if (d.row_period > 0 && (m % d.row_period) >= d.row_valid) {
+                    v = 0.f;
+                    if (Cp) Cp[(int64_t)m * d.ldc + n] = 0.f;
+                }
+                float* c = C + (int64_t)m * d.ldc + n;
+                *c = d.accumulate ? (*c + v) : v;
+            }
+        }
+    }
+}
+
+template <int BN, int PREC>
+static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    const bool akc = g.d.a_kcontig != 0, bkc = g.d.b_kcontig != 0;
+    if (akc && bkc) hipLaunchKernelGGL((k_gemm<BN, PREC, true, true>), grid, dim3(G_NT), 0, st, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((k_gemm<BN, PREC, true, false>), grid, dim3(G_NT), 0, st, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((k_gemm<BN, PREC, false, true>), grid, dim3(G_NT), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<BN, PREC, false, false>), grid, dim3(G_NT), 0, st, g);
+}
+
+paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
+    if (!d.A || !d.B || !d.C) PAA_FAIL(PAA_ERR_ARG, "gemm: null operand");
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0 || d.batch2 <= 0) PAA_FAIL(PAA_ERR_SIZE, "gemm: bad dims %d %d %d", d.M, d.N, d.K);
+    if ((d.lda & 3) || (d.ldb & 3) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15))
+        PAA_FAIL(PAA_ERR_ARG, "gemm: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+    if ((d.a_s1 & 3) || (d.a_s2 & 3) || (d.b_s1 & 3) || (d.b_s2 & 3)) PAA_FAIL(PAA_ERR_ARG, "gemm: batch strides must be multiples of 4");
+    if (d.a_kseg > 0 && ((d.a_kseg & 3) || (d.a_kseg_stride & 3) || !d.a_kcontig)) PAA_FAIL(PAA_ERR_ARG, "gemm: bad K segmentation");
+    if (d.a_window && d.a_kseg <= 0) PAA_FAIL(PAA_ERR_ARG, "gemm: a_window needs a_kseg");
+    if (d.act == PAA_ACT_GELU_GRAD && !d.aux) PAA_FAIL(PAA_ERR_ARG, "gemm: GELU_GRAD needs aux");
+    GemmArgs g;
+    g.d = d;
+    const bool narrow = d.N <= 64;
+    const int bn = narrow ? 64 : 128;
+    g.tiles_m = cdiv(d.M, G_BM);
+    g.tiles_n = cdiv(d.N, bn);
+    dim3 grid(g.tiles_m * g.tiles_n, d.batch);
+    if (narrow) { if (d.precision) launch_gemm<64, 1>(g, grid, st); else launch_gemm<64, 0>(g, grid, st); }
+    else { if (d.precision) launch_gemm<128, 1>(g, grid, st); else launch_gemm<128, 0>(g, grid, st); }
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+}  // namespace paa
+
+extern "C" paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream) {
+    if (!d) { paa::set_error("paa_gemm: null descriptor"); return PAA_ERR_ARG; }
+    return paa::gemm(*d, (hipStream_t)stream);
+}

@@ -1,0 +1,567 @@
+// Wav2Vec2ForCTC forward + CTC + backward-to-waveform, orchestrated over the gfx950 kernels.
+//
+// Replaces, for the PGD step (training_utils/train.py:136-158 of the reference):
+//   core/loss_helpers.py:21  model(input_values=perturbed, labels=labels)   [HF modeling_wav2vec2.py:1667-1736]
+//   train.py:158             (direction * loss).backward()                   [input gradient only]
+//
+// Layout.  Every activation is channel-last f32.  The feature encoder keeps P_i >= T_i rows per clip
+// with P_{i-1} = stride_i * P_i, so layer i's im2col matrix over the WHOLE batch is a plain strided view
+// of layer i-1's output (row m starts at row stride_i*m, K = k_i*C contiguous floats, lda = stride_i*C):
+// each strided 1-D convolution is ONE GEMM with overlapping A rows, and its input gradient is one GEMM
+// per residue class of the stride.  Pad rows are kept at zero.  The transformer runs on the same padded
+// row space (M = B * P_last); attention and the grouped positional convolution address clips
+// individually through the GEMM's batch strides / time window.
+// No weight gradients are computed (the reference computes and discards them).
+#include <map>
+#include <string>
+#include <vector>
+
+#include "model_kernels.h"
+
+using namespace paa;
+
+namespace {
+
+struct ConvL {
+    int cin, cout, k, s, T, P;
+    const float *w = nullptr, *b = nullptr, *g = nullptr, *beta = nullptr;
+    std::vector<const float*> wd;      // per residue class of the stride: [cin][(Q+1)*cout]
+    std::vector<int> wdQ;
+    float *pre = nullptr, *act = nullptr, *cv = nullptr, *row_stats = nullptr;
+};
+
+struct EncL {
+    const float *wqkv, *bqkv, *wqkv_t, *wo, *bo, *wo_t, *ln1_g, *ln1_b, *w1, *b1, *w1_t, *w2, *b2, *w2_t, *ln2_g, *ln2_b;
+    float *qkv, *P, *ln1_in, *st1, *fpre, *ln2_in, *st2;
+};
+
+__global__ void k_copy_logits(const float* __restrict__ src, float* __restrict__ dst, int B, int T, int P, int V) {
+    const int64_t n = (int64_t)B * T * V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % V);
+        const int64_t r = i / V;
+        const int t = (int)(r % T), b = (int)(r / T);
+        dst[i] = src[((int64_t)b * P + t) * V + v];
+    }
+}
+
+// out[b][t][c] = dy[b][t][c] * gelu'(pre[b][t][c]) for valid rows
+__global__ void k_mul_gelu_grad(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ out,
+                                int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = dy[i] * gelu_grad_f(pre[i]);
+}
+
+}  // namespace
+
+struct paa_model {
+    paa_arch a;
+    int Bmax, L, prec;
+    int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
+    std::vector<ConvL> conv;
+    std::vector<EncL> enc;
+    std::map<std::string, std::pair<const float*, int64_t>> tensors;
+    // weights
+    const float *fp_ln_g, *fp_ln_b, *fp_w, *fp_b, *fp_wt, *pc_w, *pc_b, *pc_wd, *enc_ln_g, *enc_ln_b, *lm_w, *lm_b, *lm_wt;
+    // workspace
+    float* arena = nullptr;
+    int64_t arena_floats = 0;
+    float *gn_stats, *gn_bsums, *c0_part, *G;
+    float *gbuf[2];
+    float *fn, *fp_stats, *h0, *pos_pre, *hsum, *enc_stats, *xa, *xb, *ctx, *fact, *xfinal, *final_in;
+    float *logits, *dlogits, *nll, *ctc_work;
+    float *dxa, *dxb, *dqkv, *dctx, *dP, *dfpre, *dpos, *dh0, *dfn;
+    int S_cap;
+};
+
+static const float* find(paa_model* m, const std::string& n, int64_t numel, paa_status* st) {
+    auto it = m->tensors.find(n);
+    if (it == m->tensors.end()) { set_error("missing weight tensor '" + n + "'"); *st = PAA_ERR_MISSING; return nullptr; }
+    if (it->second.second != numel) {
+        set_error("weight tensor '" + n + "' has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel));
+        *st = PAA_ERR_SIZE;
+        return nullptr;
+    }
+    return it->second.first;
+}
+#define NEED(dst, name, numel) do { paa_status _st = PAA_OK; dst = find(m, name, numel, &_st); if (_st != PAA_OK) { paa_model_destroy(m); return _st; } } while (0)
+
+extern "C" void paa_model_destroy(paa_model* m) {
+    if (!m) return;
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+}
+extern "C" int64_t paa_model_workspace_bytes(const paa_model* m) { return m ? m->arena_floats * 4 : 0; }
+extern "C" int paa_model_frames(const paa_model* m) { return m ? m->T : 0; }
+
+extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, const paa_tensor* tensors, int n_tensors,
+                                       int max_batch, int length, int precision) {
+    if (!out || !arch || !tensors) PAA_FAIL(PAA_ERR_ARG, "paa_model_create: null argument");
+    const paa_arch& a = *arch;
+    if (a.n_conv < 2 || a.n_conv > 8) PAA_FAIL(PAA_ERR_ARG, "n_conv=%d unsupported", a.n_conv);
+    if (a.hidden % a.heads || (a.hidden / a.heads) % 4 || a.hidden % 4 || a.ffn % 4 || a.vocab % 4)
+        PAA_FAIL(PAA_ERR_ARG, "hidden/heads/ffn/vocab must give 16-byte aligned rows");
+    if (a.hidden % a.pos_groups || (a.hidden / a.pos_groups) % 4) PAA_FAIL(PAA_ERR_ARG, "pos-conv group width must be a multiple of 4");
+    for (int i = 0; i < a.n_conv; ++i) if (a.conv_dim[i] % 4) PAA_FAIL(PAA_ERR_ARG, "conv_dim must be multiples of 4");
+    if (max_batch < 1 || length < 1) PAA_FAIL(PAA_ERR_SIZE, "max_batch/length");
+    paa_model* m = new paa_model();
+    m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
+    for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
+
+    // ---- shapes: conv output lengths and the padded row counts (P_{i-1} = s_i * P_i) ----
+    const int nc = a.n_conv;
+    m->conv.resize(nc);
+    int len = length;
+    for (int i = 0; i < nc; ++i) {
+        ConvL& c = m->conv[i];
+        c.cin = i ? a.conv_dim[i - 1] : 1; c.cout = a.conv_dim[i]; c.k = a.conv_kernel[i]; c.s = a.conv_stride[i];
+        if (len < c.k) { paa_model_destroy(m); PAA_FAIL(PAA_ERR_SIZE, "length %d too short for the feature encoder", length); }
+        len = (len - c.k) / c.s + 1;
+        c.T = len;
+    }
+    m->T = m->conv[nc - 1].T;
+    for (int extra = 1;; ++extra) {
+        int p = m->T + extra;
+        bool ok = true;
+        for (int i = nc - 1; i >= 0; --i) {
+            m->conv[i].P = p;
+            if (p < m->conv[i].T) ok = false;
+            p *= m->conv[i].s;
+        }
+        if (ok) break;
+        if (extra > 64) { paa_model_destroy(m); PAA_FAIL(PAA_ERR_SIZE, "cannot find a padded layout for this conv stack"); }
+    }
+    m->P = m->conv[nc - 1].P;
+    m->Tp = (m->T + 31) / 32 * 32;
+    m->M = max_batch * m->P;
+    const int H = a.hidden, F = a.ffn, V = a.vocab, nh = a.heads, Hg = H / a.pos_groups, C6 = a.conv_dim[nc - 1];
+    const int B = max_batch;
+
+    // ---- weights ----
+    for (int i = 0; i < nc; ++i) {
+        ConvL& c = m->conv[i];
+        const std::string p = "c" + std::to_string(i);
+        NEED(c.w, p + ".w", (int64_t)c.cout * c.k * c.cin);
+        if (a.conv_bias) NEED(c.b, p + ".b", c.cout);
+        if ((a.feat_norm_layer == 0 && i == 0) || a.feat_norm_layer == 1) { NEED(c.g, p + ".g", c.cout); NEED(c.beta, p + ".beta", c.cout); }
+        if (i > 0) {
+            for (int rho = 0; rho < c.s; ++rho) {
+                if (rho > c.k - 1) { c.wd.push_back(nullptr); c.wdQ.push_back(-1); continue; }
+                const int Q = (c.k - 1 - rho) / c.s;
+                const float* w;
+                NEED(w, p + ".wd" + std::to_string(rho), (int64_t)c.cin * (Q + 1) * c.cout);
+                c.wd.push_back(w); c.wdQ.push_back(Q);
+            }
+        }
+    }
+    NEED(m->fp_ln_g, "fp.ln_g", C6); NEED(m->fp_ln_b, "fp.ln_b", C6);
+    NEED(m->fp_w, "fp.w", (int64_t)H * C6); NEED(m->fp_b, "fp.b", H); NEED(m->fp_wt, "fp.wt", (int64_t)H * C6);
+    NEED(m->pc_w, "pc.w", (int64_t)H * Hg * a.pos_k); NEED(m->pc_b, "pc.b", H); NEED(m->pc_wd, "pc.wd", (int64_t)H * Hg * a.pos_k);
+    NEED(m->enc_ln_g, "enc.ln_g", H); NEED(m->enc_ln_b, "enc.ln_b", H);
+    NEED(m->lm_w, "lm.w", (int64_t)V * H); NEED(m->lm_b, "lm.b", V); NEED(m->lm_wt, "lm.wt", (int64_t)V * H);
+    m->enc.resize(a.layers);
+    for (int l = 0; l < a.layers; ++l) {
+        EncL& e = m->enc[l];
+        const std::string p = "L" + std::to_string(l);
+        NEED(e.wqkv, p + ".wqkv", (int64_t)3 * H * H); NEED(e.bqkv, p + ".bqkv", 3 * H); NEED(e.wqkv_t, p + ".wqkv_t", (int64_t)3 * H * H);
+        NEED(e.wo, p + ".wo", (int64_t)H * H); NEED(e.bo, p + ".bo", H); NEED(e.wo_t, p + ".wo_t", (int64_t)H * H);
+        NEED(e.ln1_g, p + ".ln1_g", H); NEED(e.ln1_b, p + ".ln1_b", H);
+        NEED(e.w1, p + ".w1", (int64_t)F * H); NEED(e.b1, p + ".b1", F); NEED(e.w1_t, p + ".w1_t", (int64_t)F * H);
+        NEED(e.w2, p + ".w2", (int64_t)F * H); NEED(e.b2, p + ".b2", H); NEED(e.w2_t, p + ".w2_t", (int64_t)F * H);
+        NEED(e.ln2_g, p + ".ln2_g", H); NEED(e.ln2_b, p + ".ln2_b", H);
+    }
+
+    // ---- workspace arena (two passes: size, then carve) ----
+    m->S_cap = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int64_t off = 0;
+        auto take = [&](int64_t n) -> float* {
+            n = (n + 63) / 64 * 64;          // keep every buffer 256-byte aligned
+            float* p = pass ? m->arena + off : nullptr;
+            off += n;
+            return p;
+        };
+        const int64_t GUARD = 8;             // zero rows before / after a row-matrix (dgrad look-back, im2col look-ahead)
+        int maxC = 0;
+        for (int i = 0; i < nc; ++i) maxC = std::max(maxC, a.conv_dim[i]);
+        for (int i = 0; i < nc; ++i) {
+            ConvL& c = m->conv[i];
+            const int64_t n = ((int64_t)B * c.P + GUARD) * c.cout;
+            c.pre = take(n); c.act = take(n);
+            if (a.feat_norm_layer) { if (i) c.cv = take(n); c.row_stats = take((int64_t)B * c.P * 2); }
+        }
+        const ConvL& c0 = m->conv[0];
+        m->gn_stats = take((int64_t)B * c0.cout * 2); m->gn_bsums = take((int64_t)B * c0.cout * 2);
+        m->c0_part = take((int64_t)B * conv0_chunks(c0.T) * c0.cout * 2);
+        m->G = take((int64_t)B * c0.P * c0.k);
+        for (int j = 0; j < 2; ++j) {
+            float* p = take(((int64_t)B * c0.P + 2 * GUARD) * maxC);
+            m->gbuf[j] = pass ? p + GUARD * maxC : nullptr;
+        }
+        const int64_t MH = (int64_t)m->M * H, MF = (int64_t)m->M * F;
+        m->fn = take((int64_t)m->M * C6); m->fp_stats = take((int64_t)m->M * 2);
+        m->h0 = take(MH); m->pos_pre = take(MH); m->hsum = take(MH); m->enc_stats = take((int64_t)m->M * 2);
+        m->xa = take(MH); m->xb = take(MH); m->ctx = take(MH); m->fact = take(MF); m->xfinal = take(MH); m->final_in = take(MH);
+        const int64_t PM = (int64_t)B * nh * m->Tp * m->Tp;
+        for (int l = 0; l < a.layers; ++l) {
+            EncL& e = m->enc[l];
+            e.qkv = take(3 * MH); e.P = take(PM); e.ln1_in = take(MH); e.st1 = take((int64_t)m->M * 2);
+            e.fpre = take(MF); e.ln2_in = take(MH); e.st2 = take((int64_t)m->M * 2);
+        }
+        m->logits = take((int64_t)m->M * V); m->dlogits = take((int64_t)m->M * V); m->nll = take(B);
+        m->S_cap = std::max(1, std::min(4000, m->T));     // labels longer than T_e are infeasible anyway
+        m->ctc_work = take((int64_t)B * ctc_work_floats_per_clip(m->T, V, m->S_cap));
+        m->dxa = take(MH); m->dxb = take(MH); m->dqkv = take(3 * MH); m->dctx = take(MH); m->dP = take(PM);
+        m->dfpre = take(MF); m->dpos = take(MH); m->dh0 = take(MH); m->dfn = take((int64_t)m->M * C6);
+        if (!pass) {
+            m->arena_floats = off;
+            hipError_t e = hipMalloc(&m->arena, sizeof(float) * off);
+            if (e != hipSuccess) {
+                set_error(std::string("hipMalloc of the model workspace (") + std::to_string(off * 4 >> 20) + " MiB): " + hipGetErrorString(e));
+                m->arena = nullptr; paa_model_destroy(m); return PAA_ERR_HIP;
+            }
+            e = hipMemset(m->arena, 0, sizeof(float) * off);
+            if (e != hipSuccess) { set_error(std::string("hipMemset: ") + hipGetErrorString(e)); paa_model_destroy(m); return PAA_ERR_HIP; }
+        }
+    }
+    *out = m;
+    return PAA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static paa_gemm_desc gd(const paa_model* m, const float* A, const float* Bm, float* C, int M, int N, int K, int64_t lda,
+                        int64_t ldb, int64_t ldc) {
+    paa_gemm_desc d{};
+    d.A = A; d.B = Bm; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
+    d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;
+    return d;
+}
+
+static paa_status linear(const paa_model* m, const float* x, const float* w, const float* bias, float* y, int M, int N,
+                         int K, hipStream_t st, const float* residual = nullptr, int act = 0, float* pre = nullptr,
+                         const float* aux = nullptr) {
+    paa_gemm_desc d = gd(m, x, w, y, M, N, K, K, K, N);
+    d.bias = bias; d.residual = residual; d.ld_res = N; d.act = act; d.C_pre = pre; d.aux = aux; d.ld_aux = N;
+    return gemm(d, st);
+}
+
+static paa_status forward(paa_model* m, const float* clean, const float* p, int clamp, int B, hipStream_t st) {
+    const paa_arch& a = m->a;
+    const int nc = a.n_conv, H = a.hidden, F = a.ffn, V = a.vocab, nh = a.heads, hd = H / nh, G = a.pos_groups, Hg = H / G;
+    const int M = B * m->P, T = m->T, P = m->P, Tp = m->Tp;
+    // ---- feature encoder ----
+    {
+        ConvL& c = m->conv[0];
+        Conv0Args ca{};
+        ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
+        ca.k = c.k; ca.stride = c.s; ca.w = c.w; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
+        ca.pre = c.pre; ca.act = c.act; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
+        if (a.feat_norm_layer) PAA_TRY(conv0_ln_forward(ca, st)); else PAA_TRY(conv0_gn_forward(ca, m->c0_part, st));
+    }
+    for (int i = 1; i < nc; ++i) {
+        ConvL& c = m->conv[i];
+        const ConvL& pr = m->conv[i - 1];
+        const int K = c.k * c.cin;
+        paa_gemm_desc d = gd(m, pr.act, c.w, nullptr, B * c.P, c.cout, K, (int64_t)c.s * c.cin, K, c.cout);
+        d.bias = c.b; d.row_period = c.P; d.row_valid = c.T;
+        if (a.feat_norm_layer) {
+            d.C = c.cv;
+            PAA_TRY(gemm(d, st));
+            PAA_TRY(layernorm_fwd(c.cv, c.g, c.beta, c.pre, c.row_stats, B * c.P, c.cout, 1e-5f, c.act, st));
+        } else {
+            d.C = c.act; d.C_pre = c.pre; d.act = PAA_ACT_GELU;
+            PAA_TRY(gemm(d, st));
+        }
+    }
+    // ---- feature projection: LN + Linear (pad rows forced to zero) ----
+    const ConvL& cl = m->conv[nc - 1];
+    PAA_TRY(layernorm_fwd(cl.act, m->fp_ln_g, m->fp_ln_b, m->fn, m->fp_stats, M, cl.cout, a.ln_eps, nullptr, st));
+    {
+        paa_gemm_desc d = gd(m, m->fn, m->fp_w, m->h0, M, H, cl.cout, cl.cout, cl.cout, H);
+        d.bias = m->fp_b; d.row_period = P; d.row_valid = T;
+        PAA_TRY(gemm(d, st));
+    }
+    // ---- positional conv (grouped, k taps, zero padded in time per clip) + GELU + residual ----
+    float* enc_in = a.stable_ln ? m->enc[0].ln1_in : m->hsum;
+    {
+        const int K = a.pos_k * Hg;
+        paa_gemm_desc d = gd(m, m->h0, m->pc_w, enc_in, T, Hg, K, H, K, H);
+        d.a_kseg = Hg; d.a_kseg_stride = H; d.a_window = 1; d.a_pad = a.pos_k / 2; d.a_rows_valid = T;
+        d.batch = B * G; d.batch2 = G;
+        d.a_s1 = (int64_t)P * H; d.a_s2 = Hg; d.b_s1 = 0; d.b_s2 = (int64_t)Hg * K; d.c_s1 = (int64_t)P * H; d.c_s2 = Hg;
+        d.bias = m->pc_b; d.bias_s2 = Hg; d.act = PAA_ACT_GELU; d.C_pre = m->pos_pre;
+        d.residual = m->h0; d.ld_res = H; d.res_s1 = (int64_t)P * H; d.res_s2 = Hg;
+        PAA_TRY(gemm(d, st));
+    }
+    const float* x = enc_in;
+    if (!a.stable_ln) {
+        PAA_TRY(layernorm_fwd(m->hsum, m->enc_ln_g, m->enc_ln_b, m->xa, m->enc_stats, M, H, a.ln_eps, nullptr, st));
+        x = m->xa;
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < a.layers; ++l) {
+        EncL& e = m->enc[l];
+        const float* attn_in = x;
+        if (a.stable_ln) {   // x is e.ln1_in
+            PAA_TRY(layernorm_fwd(x, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, nullptr, st));
+            attn_in = m->xb;
+        }
+        PAA_TRY(linear(m, attn_in, e.wqkv, e.bqkv, e.qkv, M, 3 * H, H, st));
+        {   // S = Q K^T  per (clip, head)
+            paa_gemm_desc d = gd(m, e.qkv, e.qkv + H, e.P, T, T, hd, 3 * H, 3 * H, Tp);
+            d.batch = B * nh; d.batch2 = nh;
+            d.a_s1 = (int64_t)P * 3 * H; d.a_s2 = hd; d.b_s1 = (int64_t)P * 3 * H; d.b_s2 = hd;
+            d.c_s1 = (int64_t)nh * Tp * Tp; d.c_s2 = (int64_t)Tp * Tp;
+            PAA_TRY(gemm(d, st));
+        }
+        PAA_TRY(softmax_fwd(e.P, B * nh, T, Tp, T, Tp, scale, st));
+        {   // ctx = P V
+            paa_gemm_desc d = gd(m, e.P, e.qkv + 2 * H, m->ctx, T, hd, T, Tp, 3 * H, H);
+            d.b_kcontig = 0;
+            d.batch = B * nh; d.batch2 = nh;
+            d.a_s1 = (int64_t)nh * Tp * Tp; d.a_s2 = (int64_t)Tp * Tp; d.b_s1 = (int64_t)P * 3 * H; d.b_s2 = hd;
+            d.c_s1 = (int64_t)P * H; d.c_s2 = hd;
+            PAA_TRY(gemm(d, st));
+        }
+        if (!a.stable_ln) {
+            PAA_TRY(linear(m, m->ctx, e.wo, e.bo, e.ln1_in, M, H, H, st, x));                       // r1 = x + attn
+            PAA_TRY(layernorm_fwd(e.ln1_in, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, nullptr, st));   // y1
+            PAA_TRY(linear(m, m->xb, e.w1, e.b1, m->fact, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
+            PAA_TRY(linear(m, m->fact, e.w2, e.b2, e.ln2_in, M, H, F, st, m->xb));                 // r2 = y1 + ffn
+            float* xo = (l == a.layers - 1) ? m->xfinal : m->xa;
+            PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, xo, e.st2, M, H, a.ln_eps, nullptr, st));
+            x = xo;
+        } else {
+            PAA_TRY(linear(m, m->ctx, e.wo, e.bo, e.ln2_in, M, H, H, st, x));                       // r1 = x + attn
+            PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, m->xb, e.st2, M, H, a.ln_eps, nullptr, st));
+            PAA_TRY(linear(m, m->xb, e.w1, e.b1, m->fact, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
+            float* xo = (l == a.layers - 1) ? m->final_in : m->enc[l + 1].ln1_in;
+            PAA_TRY(linear(m, m->fact, e.w2, e.b2, xo, M, H, F, st, e.ln2_in));                     // r2 = r1 + ffn
+            x = xo;
+        }
+    }
+    if (a.stable_ln) {
+        PAA_TRY(layernorm_fwd(x, m->enc_ln_g, m->enc_ln_b, m->xfinal, m->enc_stats, M, H, a.ln_eps, nullptr, st));
+    }
+    PAA_TRY(linear(m, m->xfinal, m->lm_w, m->lm_b, m->logits, M, V, H, st));
+    return PAA_OK;
+}
+
+static paa_status backward(paa_model* m, const float* clean, const float* p, int clamp, int B, float* grad, hipStream_t st) {
+    const paa_arch& a = m->a;
+    const int nc = a.n_conv, H = a.hidden, F = a.ffn, V = a.vocab, nh = a.heads, hd = H / nh, G = a.pos_groups, Hg = H / G;
+    const int M = B * m->P, T = m->T, P = m->P, Tp = m->Tp;
+    const float scale = 1.0f / sqrtf((float)hd);
+    // dlogits -> dx
+    float* dx = m->dxa;
+    float* dx2 = m->dxb;
+    PAA_TRY(linear(m, m->dlogits, m->lm_wt, nullptr, dx, M, H, V, st));
+    if (a.stable_ln) {
+        PAA_TRY(layernorm_bwd(dx, m->final_in, m->enc_ln_g, m->enc_stats, nullptr, nullptr, dx, M, H, st));
+    }
+    for (int l = a.layers - 1; l >= 0; --l) {
+        EncL& e = m->enc[l];
+        const float* dattn_out;      // gradient wrt the attention block's output (= gradient of r1)
+        if (!a.stable_ln) {
+            PAA_TRY(layernorm_bwd(dx, e.ln2_in, e.ln2_g, e.st2, nullptr, nullptr, dx, M, H, st));                 // dr2
+            PAA_TRY(linear(m, dx, e.w2_t, nullptr, m->dfpre, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
+            PAA_TRY(linear(m, m->dfpre, e.w1_t, nullptr, dx2, M, H, F, st, dx));                                     // dy1 = dr2 + ...
+            PAA_TRY(layernorm_bwd(dx2, e.ln1_in, e.ln1_g, e.st1, nullptr, nullptr, dx2, M, H, st));               // dr1
+            dattn_out = dx2;
+        } else {
+            PAA_TRY(linear(m, dx, e.w2_t, nullptr, m->dfpre, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
+            PAA_TRY(linear(m, m->dfpre, e.w1_t, nullptr, dx2, M, H, F, st));                                         // dn2
+            PAA_TRY(layernorm_bwd(dx2, e.ln2_in, e.ln2_g, e.st2, dx, nullptr, dx2, M, H, st));                      // dr1 = dr2 + LN2'
+            dattn_out = dx2;
+        }
+        PAA_TRY(linear(m, dattn_out, e.wo_t, nullptr, m->dctx, M, H, H, st));
+        const int64_t sq = (int64_t)P * 3 * H, sp = (int64_t)nh * Tp * Tp, sp2 = (int64_t)Tp * Tp, sc = (int64_t)P * H;
+        {   // dP = dctx V^T
+            paa_gemm_desc d = gd(m, m->dctx, e.qkv + 2 * H, m->dP, T, T, hd, H, 3 * H, Tp);
+            d.batch = B * nh; d.batch2 = nh;
+            d.a_s1 = sc; d.a_s2 = hd; d.b_s1 = sq; d.b_s2 = hd; d.c_s1 = sp; d.c_s2 = sp2;
+            PAA_TRY(gemm(d, st));
+        }
+        {   // dV = P^T dctx
+            paa_gemm_desc d = gd(m, e.P, m->dctx, m->dqkv + 2 * H, T, hd, T, Tp, H, 3 * H);
+            d.a_kcontig = 0; d.b_kcontig = 0;
+            d.batch = B * nh; d.batch2 = nh;
+            d.a_s1 = sp; d.a_s2 = sp2; d.b_s1 = sc; d.b_s2 = hd; d.c_s1 = sq; d.c_s2 = hd;
+            PAA_TRY(gemm(d, st));
+        }
+        PAA_TRY(softmax_bwd(m->dP, e.P, B * nh, T, Tp, T, Tp, scale, st));
+        {   // dQ = dS K
+            paa_gemm_desc d = gd(m, m->dP, e.qkv + H, m->dqkv, T, hd, T, Tp, 3 * H, 3 * H);
+            d.b_kcontig = 0;
+            d.batch = B * nh; d.batch2 = nh;
+            d.a_s1 = sp; d.a_s2 = sp2; d.b_s1 = sq; d.b_s2 = hd; d.c_s1 = sq; d.c_s2 = hd;
+            PAA_TRY(gemm(d, st));
+        }
+        {   // dK = dS^T Q
+            paa_gemm_desc d = gd(m, m->dP, e.qkv, m->dqkv + H, T, hd, T, Tp, 3 * H, 3 * H);
+            d.a_kcontig = 0; d.b_kcontig = 0;
+            d.batch = B * nh; d.batch2 = nh;
+            d.a_s1 = sp; d.a_s2 = sp2; d.b_s1 = sq; d.b_s2 = hd; d.c_s1 = sq; d.c_s2 = hd;
+            PAA_TRY(gemm(d, st));
+        }
+        if (!a.stable_ln) {
+            PAA_TRY(linear(m, m->dqkv, e.wqkv_t, nullptr, dx, M, H, 3 * H, st, dattn_out));       // dx = dr1 + dqkv Wqkv
+        } else {
+            PAA_TRY(linear(m, m->dqkv, e.wqkv_t, nullptr, dx, M, H, 3 * H, st));                  // dn1
+            PAA_TRY(layernorm_bwd(dx, e.ln1_in, e.ln1_g, e.st1, dattn_out, nullptr, dx, M, H, st));   // dx = dr1 + LN1'
+        }
+    }
+    if (!a.stable_ln) {
+        PAA_TRY(layernorm_bwd(dx, m->hsum, m->enc_ln_g, m->enc_stats, nullptr, nullptr, dx, M, H, st));   // d hsum
+    }
+    // ---- positional conv backward: dh0 = dhsum + convT(dhsum * gelu'(pos_pre)) ----
+    hipLaunchKernelGGL(k_mul_gelu_grad, dim3(std::min(cdiv((int64_t)M * H, 256), 4096)), dim3(256), 0, st, (const float*)dx,
+                       (const float*)m->pos_pre, m->dpos, (int64_t)M * H);
+    PAA_LAUNCH_CHECK();
+    {
+        const int K = a.pos_k * Hg;
+        paa_gemm_desc d = gd(m, m->dpos, m->pc_wd, m->dh0, T, Hg, K, H, K, H);
+        d.a_kseg = Hg; d.a_kseg_stride = H; d.a_window = 1; d.a_pad = a.pos_k - 1 - a.pos_k / 2; d.a_rows_valid = T;
+        d.batch = B * G; d.batch2 = G;
+        d.a_s1 = (int64_t)P * H; d.a_s2 = Hg; d.b_s1 = 0; d.b_s2 = (int64_t)Hg * K; d.c_s1 = (int64_t)P * H; d.c_s2 = Hg;
+        d.residual = dx; d.ld_res = H; d.res_s1 = (int64_t)P * H; d.res_s2 = Hg;
+        PAA_TRY(gemm(d, st));
+    }
+    // ---- feature projection backward ----
+    const ConvL& cl = m->conv[nc - 1];
+    PAA_TRY(linear(m, m->dh0, m->fp_wt, nullptr, m->dfn, M, cl.cout, H, st));
+    // gradient wrt conv_{last}'s GELU output, then through the GELU
+    float* gz = m->gbuf[(nc - 1) & 1];
+    PAA_TRY(layernorm_bwd(m->dfn, cl.act, m->fp_ln_g, m->fp_stats, nullptr, nullptr, gz, M, cl.cout, st));
+    hipLaunchKernelGGL(k_mul_gelu_grad, dim3(std::min(cdiv((int64_t)M * cl.cout, 256), 4096)), dim3(256), 0, st,
+                       (const float*)gz, (const float*)cl.pre, gz, (int64_t)M * cl.cout);
+    PAA_LAUNCH_CHECK();
+    // ---- feature encoder backward ----
+    for (int i = nc - 1; i >= 1; --i) {
+        ConvL& c = m->conv[i];
+        const ConvL& pr = m->conv[i - 1];
+        float* gin = m->gbuf[i & 1];           // gradient wrt layer i's norm output (pre-GELU)
+        float* gout = m->gbuf[(i - 1) & 1];
+        if (a.feat_norm_layer)                 // through LayerNorm_i to the raw conv output
+            PAA_TRY(layernorm_bwd(gin, c.cv, c.g, c.row_stats, nullptr, nullptr, gin, B * c.P, c.cout, st));
+        for (int rho = 0; rho < c.s; ++rho) {
+            const int Q = c.wdQ[rho];
+            const int64_t ldo = (int64_t)c.s * c.cin;
+            if (Q < 0) {   // no tap reaches this residue class: zero gradient rows
+                PAA_HIP(hipMemset2DAsync(gout + (int64_t)rho * c.cin, ldo * 4, 0, (size_t)c.cin * 4, (size_t)B * c.P, st));
+                continue;
+            }
+            const int K = (Q + 1) * c.cout;
+            paa_gemm_desc d = gd(m, gin - (int64_t)Q * c.cout, c.wd[rho], gout + (int64_t)rho * c.cin, B * c.P, c.cin, K,
+                                 c.cout, K, ldo);
+            d.act = PAA_ACT_GELU_GRAD; d.aux = pr.pre + (int64_t)rho * c.cin; d.ld_aux = ldo;
+            PAA_TRY(gemm(d, st));
+        }
+    }
+    {
+        ConvL& c = m->conv[0];
+        Conv0Args ca{};
+        ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
+        ca.k = c.k; ca.stride = c.s; ca.w = c.w; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
+        ca.gn_stats = m->gn_stats; ca.gn_bsums = m->gn_bsums; ca.row_stats = c.row_stats; ca.dpre = m->gbuf[0]; ca.G = m->G;
+        PAA_TRY(conv0_backward(ca, a.feat_norm_layer, m->c0_part, grad, st));
+    }
+    return PAA_OK;
+}
+
+extern "C" paa_status paa_model_fwd_bwd(paa_model* m, const float* d_clean, const float* d_p, const int32_t* d_labels, int B,
+                                        int S_max, int direction, float* d_grad, float* d_logits, float* d_stats,
+                                        void* stream) {
+    if (!m || !d_clean) PAA_FAIL(PAA_ERR_ARG, "paa_model_fwd_bwd: null argument");
+    if (B < 1 || B > m->Bmax) PAA_FAIL(PAA_ERR_SIZE, "batch %d exceeds max_batch %d", B, m->Bmax);
+    if (d_labels && (S_max < 1 || S_max > m->S_cap)) PAA_FAIL(PAA_ERR_SIZE, "S_max=%d exceeds capacity %d", S_max, m->S_cap);
+    if (d_grad && !d_labels) PAA_FAIL(PAA_ERR_ARG, "gradient requested without labels");
+    hipStream_t st = (hipStream_t)stream;
+    const int clamp = d_p ? 1 : 0;
+    PAA_TRY(forward(m, d_clean, d_p, clamp, B, st));
+    const int V = m->a.vocab;
+    if (d_logits) {
+        hipLaunchKernelGGL(k_copy_logits, dim3(std::min(cdiv((int64_t)B * m->T * V, 256), 2048)), dim3(256), 0, st,
+                           (const float*)m->logits, d_logits, B, m->T, m->P, V);
+        PAA_LAUNCH_CHECK();
+    }
+    if (d_labels) {
+        PAA_TRY(ctc(m->logits, d_labels, B, m->T, m->P, V, S_max, m->a.blank, (float)direction, m->nll,
+                    d_grad ? m->dlogits : nullptr, m->ctc_work, st));
+        if (d_stats) PAA_TRY(sum_small(m->nll, B, d_stats, st));
+    }
+    if (d_grad) PAA_TRY(backward(m, d_clean, d_p, clamp, B, d_grad, st));
+    return PAA_OK;
+}
+
+// sizeof of every struct that crosses the ABI, so the host binding can verify its layout.
+extern "C" void paa_abi_sizes(int32_t* out4) {
+    out4[0] = (int32_t)sizeof(paa_params);
+    out4[1] = (int32_t)sizeof(paa_arch);
+    out4[2] = (int32_t)sizeof(paa_tensor);
+    out4[3] = (int32_t)sizeof(paa_gemm_desc);
+}
+
+// Test/diagnostic access to the internal activations (synchronous copy to host; never on the step path).
+// Names: conv{i}.pre|act|cv, fn, h0, pos_pre, hsum, xfinal, logits, dlogits, nll, G, gbuf0, gbuf1, dh0, dfn, dxa,
+//        L{l}.qkv|P|ln1_in|fpre|ln2_in.  Returns the number of floats available (0 if unknown).
+extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* host, int64_t max_floats, int B) {
+    if (!m || !name) return 0;
+    const std::string n(name);
+    const paa_arch& a = m->a;
+    const int nc = a.n_conv, H = a.hidden, F = a.ffn, V = a.vocab;
+    const int64_t M = (int64_t)B * m->P;
+    const float* p = nullptr;
+    int64_t cnt = 0;
+    for (int i = 0; i < nc && !p; ++i) {
+        const ConvL& c = m->conv[i];
+        const std::string b = "conv" + std::to_string(i);
+        const int64_t sz = (int64_t)B * c.P * c.cout;
+        if (n == b + ".pre") { p = c.pre; cnt = sz; }
+        else if (n == b + ".act") { p = c.act; cnt = sz; }
+        else if (n == b + ".cv" && c.cv) { p = c.cv; cnt = sz; }
+    }
+    for (int l = 0; l < a.layers && !p; ++l) {
+        const EncL& e = m->enc[l];
+        const std::string b = "L" + std::to_string(l);
+        if (n == b + ".qkv") { p = e.qkv; cnt = M * 3 * H; }
+        else if (n == b + ".P") { p = e.P; cnt = (int64_t)B * a.heads * m->Tp * m->Tp; }
+        else if (n == b + ".ln1_in") { p = e.ln1_in; cnt = M * H; }
+        else if (n == b + ".fpre") { p = e.fpre; cnt = M * F; }
+        else if (n == b + ".ln2_in") { p = e.ln2_in; cnt = M * H; }
+    }
+    if (!p) {
+        const ConvL& c0 = m->conv[0];
+        int maxC = 0;
+        for (int i = 0; i < nc; ++i) maxC = std::max(maxC, a.conv_dim[i]);
+        if (n == "fn") { p = m->fn; cnt = M * a.conv_dim[nc - 1]; }
+        else if (n == "h0") { p = m->h0; cnt = M * H; }
+        else if (n == "pos_pre") { p = m->pos_pre; cnt = M * H; }
+        else if (n == "hsum") { p = a.stable_ln ? m->enc[0].ln1_in : m->hsum; cnt = M * H; }
+        else if (n == "xfinal") { p = m->xfinal; cnt = M * H; }
+        else if (n == "logits") { p = m->logits; cnt = M * V; }
+        else if (n == "dlogits") { p = m->dlogits; cnt = M * V; }
+        else if (n == "nll") { p = m->nll; cnt = B; }
+        else if (n == "G") { p = m->G; cnt = (int64_t)B * c0.P * c0.k; }
+        else if (n == "gbuf0") { p = m->gbuf[0]; cnt = (int64_t)B * c0.P * maxC; }
+        else if (n == "gbuf1") { p = m->gbuf[1]; cnt = (int64_t)B * c0.P * maxC; }
+        else if (n == "dh0") { p = m->dh0; cnt = M * H; }
+        else if (n == "dfn") { p = m->dfn; cnt = M * a.conv_dim[nc - 1]; }
+        else if (n == "dxa") { p = m->dxa; cnt = M * H; }
+        else if (n == "gn_stats") { p = m->gn_stats; cnt = (int64_t)B * c0.cout * 2; }
+    }
+    if (!p) return 0;
+    if (host && max_floats > 0) {
+        if (hipDeviceSynchronize() != hipSuccess) return -1;
+        if (hipMemcpy(host, p, sizeof(float) * std::min(cnt, max_floats), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    return cnt;
+}
+// (padded rows per clip of conv layer i; i = -1: encoder frame rows P, -2: score-matrix ld Tp)
+extern "C" int paa_model_layout(const paa_model* m, int i) {
+    if (!m) return 0;
+    if (i == -1) return m->P;
+    if (i == -2) return m->Tp;
+    if (i >= 0 && i < m->a.n_conv) return m->conv[i].P;
+    return 0;
+}

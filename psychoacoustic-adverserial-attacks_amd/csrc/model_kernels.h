@@ -1,0 +1,52 @@
+// Declarations of the non-GEMM kernels (model_kernels.hip) and of the GEMM entry (gemm.hip).
+#pragma once
+#include <algorithm>
+
+#include "gemm.h"
+#include "paa_common.h"
+
+namespace paa {
+
+paa_status gemm(const paa_gemm_desc& d, hipStream_t st);
+
+paa_status layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats, int rows, int cols,
+                         float eps, float* y_act /* optional gelu(y) */, hipStream_t st);
+paa_status layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, const float* add,
+                         const float* gelu_pre, float* dx, int rows, int cols, hipStream_t st);
+// n_mat matrices of rows_per_mat valid rows (mat_rows_ld allocated rows each), `cols` valid columns, row stride ld
+paa_status softmax_fwd(float* s, int n_mat, int rows_per_mat, int mat_rows_ld, int cols, int ld, float scale,
+                       hipStream_t st);
+paa_status softmax_bwd(float* dp, const float* p, int n_mat, int rows_per_mat, int mat_rows_ld, int cols, int ld,
+                       float scale, hipStream_t st);
+
+// First feature-encoder layer (C_in = 1).  Activations are channel-last with P >= T rows per clip.
+struct Conv0Args {
+    const float* clean;      // (B, L)
+    const float* p;          // (L) or null
+    int clamp;               // clamp(clean + p, -1, 1)
+    int B, L, T, P, C, k, stride;
+    const float* w;          // [C][k]
+    const float* bias;       // [C] or null
+    const float* gamma;      // norm affine
+    const float* beta;
+    float eps;
+    float* pre;              // (B, P, C) norm output (pre-GELU)
+    float* act;              // (B, P, C) GELU(pre)
+    float* gn_stats;         // group: (B, C, 2) mean, rstd over time
+    float* gn_bsums;         // group backward: (B, C, 2) mean_t(dy), mean_t(dy * xhat)
+    float* row_stats;        // layer: (B, P, 2) mean, rstd over channels
+    const float* dpre;       // backward: (B, P, C) gradient wrt `pre`
+    float* G;                // backward: (B, P, k) per-frame, per-tap input gradient
+    float* part;             // scratch partials
+};
+paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st);
+paa_status conv0_ln_forward(const Conv0Args& a, hipStream_t st);
+paa_status conv0_backward(const Conv0Args& a, int layer_norm, float* part, float* grad, hipStream_t st);
+int conv0_chunks(int T);
+
+int64_t ctc_work_floats_per_clip(int T, int V, int S_max);
+paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
+               float grad_scale, float* nll, float* dlogits, float* work, hipStream_t st);
+paa_status sum_small(const float* x, int n, float* out, hipStream_t st);
+
+}  // namespace paa

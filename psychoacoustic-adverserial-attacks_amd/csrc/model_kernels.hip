@@ -1,0 +1,611 @@
+// Non-GEMM kernels of the Wav2Vec2 forward/backward for gfx950: layer norm, attention softmax,
+// the C_in = 1 first convolution with its GroupNorm / LayerNorm, CTC (alpha/beta in LDS), and the
+// reduction of the input gradient over the batch into the universal perturbation's gradient.
+//
+// Third-party algorithm restated (HuggingFace transformers modeling_wav2vec2.py, torch ATen):
+//   Wav2Vec2GroupNormConvLayer / Wav2Vec2LayerNormConvLayer (:275-323), nn.LayerNorm, softmax,
+//   F.ctc_loss(reduction='sum', zero_infinity=False) and its backward.
+#include "model_kernels.h"
+
+namespace paa {
+
+// ================================================================================ LayerNorm ===
+// One wave per row; rows are short (<= 4 KB) and stay in L1 across the passes.
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ g,
+                                              const float* __restrict__ b, float* __restrict__ y,
+                                              float* __restrict__ stats, int rows, int cols, float eps, int gelu,
+                                              float* __restrict__ y_act) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * cols;
+    float s = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float a = v.x - mean, bb = v.y - mean, cc = v.z - mean, dd = v.w - mean;
+        q += (a * a + bb * bb) + (cc * cc + dd * dd);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0 && stats) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float4 gg = *reinterpret_cast<const float4*>(g + c);
+        const float4 bv = *reinterpret_cast<const float4*>(b + c);
+        float4 o;
+        o.x = (v.x - mean) * rstd * gg.x + bv.x;
+        o.y = (v.y - mean) * rstd * gg.y + bv.y;
+        o.z = (v.z - mean) * rstd * gg.z + bv.z;
+        o.w = (v.w - mean) * rstd * gg.w + bv.w;
+        *reinterpret_cast<float4*>(y + (size_t)row * cols + c) = o;
+        if (gelu) {
+            float4 a;
+            a.x = gelu_f(o.x); a.y = gelu_f(o.y); a.z = gelu_f(o.z); a.w = gelu_f(o.w);
+            *reinterpret_cast<float4*>(y_act + (size_t)row * cols + c) = a;
+        }
+    }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ add];  if gelu_pre: dy *= gelu'(gelu_pre) first
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                              const float* __restrict__ g, const float* __restrict__ stats,
+                                              const float* __restrict__ add, const float* __restrict__ gelu_pre,
+                                              float* __restrict__ dx, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const size_t o = (size_t)row * cols;
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        float d = dy[o + c];
+        if (gelu_pre) d *= gelu_grad_f(gelu_pre[o + c]);
+        const float gd = g[c] * d;
+        s1 += gd;
+        s2 += gd * ((x[o + c] - mean) * rstd);
+    }
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+    for (int c = lane; c < cols; c += 64) {
+        float d = dy[o + c];
+        if (gelu_pre) d *= gelu_grad_f(gelu_pre[o + c]);
+        const float xh = (x[o + c] - mean) * rstd;
+        float v = rstd * (g[c] * d - s1 - xh * s2);
+        if (add) v += add[o + c];
+        dx[o + c] = v;
+    }
+}
+
+paa_status layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats, int rows, int cols,
+                         float eps, float* y_act, hipStream_t st) {
+    if (cols & 3) PAA_FAIL(PAA_ERR_ARG, "layernorm: cols=%d must be a multiple of 4", cols);
+    hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, g, b, y, stats, rows, cols, eps,
+                       y_act ? 1 : 0, y_act);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+paa_status layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, const float* add,
+                         const float* gelu_pre, float* dx, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, g, stats, add, gelu_pre, dx, rows, cols);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+// ================================================================================= softmax ===
+// In place on rows of `cols` valid entries with leading dimension ld; pad columns are zeroed.
+__global__ __launch_bounds__(256) void k_softmax_fwd(float* __restrict__ s, int rows, int cols, int ld, float scale,
+                                                   int rows_per_mat, int mat_rows_ld) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float* p = s + ((size_t)(r / rows_per_mat) * mat_rows_ld + (r % rows_per_mat)) * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, p[c] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += __expf(p[c] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int c = lane; c < ld; c += 64) p[c] = (c < cols) ? __expf(p[c] * scale - mx) * inv : 0.f;
+}
+
+// dS = scale * P * (dP - sum_j dP_j P_j), in place on dP.
+__global__ __launch_bounds__(256) void k_softmax_bwd(float* __restrict__ dp, const float* __restrict__ pm, int rows,
+                                                   int cols, int ld, float scale, int rows_per_mat, int mat_rows_ld) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const size_t o = ((size_t)(r / rows_per_mat) * mat_rows_ld + (r % rows_per_mat)) * ld;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) dot += dp[o + c] * pm[o + c];
+    dot = wave_sum(dot);
+    for (int c = lane; c < ld; c += 64) dp[o + c] = (c < cols) ? scale * pm[o + c] * (dp[o + c] - dot) : 0.f;
+}
+
+paa_status softmax_fwd(float* s, int n_mat, int rows_per_mat, int mat_rows_ld, int cols, int ld, float scale,
+                       hipStream_t st) {
+    const int rows = n_mat * rows_per_mat;
+    hipLaunchKernelGGL(k_softmax_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, cols, ld, scale, rows_per_mat,
+                       mat_rows_ld);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+paa_status softmax_bwd(float* dp, const float* p, int n_mat, int rows_per_mat, int mat_rows_ld, int cols, int ld,
+                       float scale, hipStream_t st) {
+    const int rows = n_mat * rows_per_mat;
+    hipLaunchKernelGGL(k_softmax_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, dp, p, rows, cols, ld, scale, rows_per_mat,
+                       mat_rows_ld);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+// ============================================================================ conv0 (C_in=1) ===
+// Input sample i of clip b: clamp(clean[b][i] + p[i], -1, 1) (train.py:136) — or clean + p unclamped
+// (evaluation.py:16) — or clean alone when p is null.  Never materialised.
+__device__ __forceinline__ float in_sample(const Conv0Args& a, int b, int i) {
+    float v = a.clean[(size_t)b * a.L + i];
+    if (a.p) {
+        v += a.p[i];
+        if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+    }
+    return v;
+}
+
+constexpr int C0_TCH = 64;   // frames per workgroup in the channel-per-thread kernels
+
+// Channel-per-thread mapping (thread owns channels tid, tid+256, ...; loops over a chunk of frames).
+// MODE 0: GroupNorm statistics partials (sum v, sum v^2)           -> part[b][chunk][c][2]
+// MODE 1: apply GroupNorm + GELU                                    -> pre[b][t][c], act[b][t][c]
+// MODE 2: backward statistics partials (sum dy, sum dy*xhat)        -> part[b][chunk][c][2]
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * C0_TCH;
+    const int nt = min(C0_TCH, a.T - t0);
+    const int span = (nt - 1) * a.stride + a.k;
+    const int span_alloc = (C0_TCH - 1) * a.stride + 10;
+    for (int i = threadIdx.x; i < span_alloc; i += 256) xs[i] = (i < span) ? in_sample(a, b, t0 * a.stride + i) : 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        float w[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[j] = (j < a.k) ? a.w[c * a.k + j] : 0.f;
+        float mean = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
+        if (MODE >= 1) {
+            mean = a.gn_stats[((size_t)b * a.C + c) * 2];
+            rstd = a.gn_stats[((size_t)b * a.C + c) * 2 + 1];
+            gam = a.gamma[c]; bet = a.beta[c];
+        }
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = 0; t < nt; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v += w[j] * xs[t * a.stride + j];
+            const size_t o = ((size_t)b * a.P + t0 + t) * a.C + c;
+            if (MODE == 0) {
+                s1 += v; s2 += v * v;
+            } else if (MODE == 1) {
+                const float y = (v - mean) * rstd * gam + bet;
+                a.pre[o] = y;
+                a.act[o] = gelu_f(y);
+            } else {
+                const float dy = a.dpre[o];
+                s1 += dy; s2 += dy * ((v - mean) * rstd);
+            }
+        }
+        if (MODE != 1) {
+            const size_t o = (((size_t)b * gridDim.x + chunk) * a.C + c) * 2;
+            a.part[o] = s1; a.part[o + 1] = s2;
+        }
+    }
+    // pad rows [T, P) of this clip are zero
+    if (MODE == 1 && chunk == gridDim.x - 1)
+        for (int t = a.T; t < a.P; ++t)
+            for (int c = threadIdx.x; c < a.C; c += 256) {
+                const size_t o = ((size_t)b * a.P + t) * a.C + c;
+                a.pre[o] = 0.f; a.act[o] = 0.f;
+            }
+}
+
+// Reduce the per-chunk partials in f64.  MODE 0: (sum, sumsq) -> (mean, rstd);  MODE 2: -> (s1/n, s2/n)
+__global__ void k_conv0_gn_finalize(const float* __restrict__ part, float* __restrict__ out, int B, int C,
+                                    int nchunk, int n, float eps, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const size_t o = (((size_t)b * nchunk + k) * C + c) * 2;
+        s1 += (double)part[o]; s2 += (double)part[o + 1];
+    }
+    if (mode == 0) {
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        out[2 * (size_t)i] = (float)mean;
+        out[2 * (size_t)i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        out[2 * (size_t)i] = (float)(s1 / n);
+        out[2 * (size_t)i + 1] = (float)(s2 / n);
+    }
+}
+
+// Wave-per-frame mapping: lane owns channels lane, lane+64, ... (C <= 512).
+// FWD_LN  : conv + bias -> LayerNorm over channels -> pre, GELU -> act, row stats (mean, rstd)
+// BWD     : dv (through GroupNorm with the precomputed batch sums, or through LayerNorm with wave sums),
+//           then G[b][t][j] = sum_c w[c][j] * dv[c]   (the transposed C_in = 1 convolution, per tap)
+enum { C0_FWD_LN = 0, C0_BWD_GN = 1, C0_BWD_LN = 2 };
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv0_rows(Conv0Args a) {
+    constexpr int MAXC = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    const int b = blockIdx.y;
+    const int nc = (a.C + 63) / 64;
+    float w[MAXC][10];
+    float gam[MAXC], bet[MAXC], bias[MAXC], mean_c[MAXC], rstd_c[MAXC], bs1[MAXC], bs2[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = (i < nc) && (c < a.C);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[i][j] = (ok && j < a.k) ? a.w[c * a.k + j] : 0.f;
+        gam[i] = ok ? a.gamma[c] : 0.f;
+        bet[i] = ok ? a.beta[c] : 0.f;
+        bias[i] = (ok && a.bias && MODE != C0_BWD_GN) ? a.bias[c] : 0.f;   // GroupNorm cancels a per-channel bias
+        if (MODE == C0_BWD_GN) {
+            mean_c[i] = ok ? a.gn_stats[((size_t)b * a.C + c) * 2] : 0.f;
+            rstd_c[i] = ok ? a.gn_stats[((size_t)b * a.C + c) * 2 + 1] : 0.f;
+            bs1[i] = ok ? a.gn_bsums[((size_t)b * a.C + c) * 2] : 0.f;
+            bs2[i] = ok ? a.gn_bsums[((size_t)b * a.C + c) * 2 + 1] : 0.f;
+        }
+    }
+    for (int t = wave_global; t < a.P; t += n_waves) {
+        const size_t row = (size_t)b * a.P + t;
+        if (t >= a.T) {                       // pad rows
+            if (MODE == C0_FWD_LN) {
+                for (int i = 0; i < nc; ++i) { const int c = lane + 64 * i; if (c < a.C) { a.pre[row * a.C + c] = 0.f; a.act[row * a.C + c] = 0.f; } }
+                if (lane == 0) { a.row_stats[2 * row] = 0.f; a.row_stats[2 * row + 1] = 0.f; }
+            } else if (lane < a.k) a.G[row * a.k + lane] = 0.f;
+            continue;
+        }
+        float xin[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xin[j] = (j < a.k) ? in_sample(a, b, t * a.stride + j) : 0.f;
+        float v[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            float acc = bias[i];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc += w[i][j] * xin[j];
+            v[i] = acc;
+            if (i < nc && lane + 64 * i < a.C) s += acc;
+        }
+        float dv[MAXC];
+        if (MODE == C0_FWD_LN || MODE == C0_BWD_LN) {
+            float mean, rstd;
+            if (MODE == C0_FWD_LN) {
+                mean = wave_sum(s) / (float)a.C;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) if (i < nc && lane + 64 * i < a.C) q += (v[i] - mean) * (v[i] - mean);
+                rstd = rsqrtf(wave_sum(q) / (float)a.C + a.eps);
+                if (lane == 0) { a.row_stats[2 * row] = mean; a.row_stats[2 * row + 1] = rstd; }
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = lane + 64 * i;
+                    if (i < nc && c < a.C) {
+                        const float y = (v[i] - mean) * rstd * gam[i] + bet[i];
+                        a.pre[row * a.C + c] = y;
+                        a.act[row * a.C + c] = gelu_f(y);
+                    }
+                }
+                continue;
+            }
+            mean = a.row_stats[2 * row]; rstd = a.row_stats[2 * row + 1];
+            float s1 = 0.f, s2 = 0.f;
+            float gd[MAXC], xh[MAXC];
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                const bool ok = i < nc && c < a.C;
+                gd[i] = ok ? gam[i] * a.dpre[row * a.C + c] : 0.f;
+                xh[i] = ok ? (v[i] - mean) * rstd : 0.f;
+                s1 += gd[i]; s2 += gd[i] * xh[i];
+            }
+            s1 = wave_sum(s1) / (float)a.C;
+            s2 = wave_sum(s2) / (float)a.C;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) dv[i] = (i < nc && lane + 64 * i < a.C) ? rstd * (gd[i] - s1 - xh[i] * s2) : 0.f;
+        } else {   // C0_BWD_GN: dv = gamma * rstd * (dy - mean_t(dy) - xhat * mean_t(dy*xhat))
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                const bool ok = i < nc && c < a.C;
+                const float dy = ok ? a.dpre[row * a.C + c] : 0.f;
+                const float xh = (v[i] - mean_c[i]) * rstd_c[i];
+                dv[i] = ok ? gam[i] * rstd_c[i] * (dy - bs1[i] - xh * bs2[i]) : 0.f;
+            }
+        }
+        float gj[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) acc += w[i][j] * dv[i];
+            gj[j] = wave_sum(acc);
+        }
+#pragma unroll
+        for (int j = 0; j < 10; ++j) if (lane == j && j < a.k) a.G[row * a.k + j] = gj[j];
+    }
+}
+
+// grad[l] = sum_b mask_b[l] * sum_{(t, j): t*stride + j = l} G[b][t][j]    (fixed summation order over b)
+__global__ void k_input_grad(Conv0Args a, float* __restrict__ grad) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.L) return;
+    float total = 0.f;
+    const float pv = a.p ? a.p[l] : 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        float gsum = 0.f;
+        // taps j = l - t*stride in [0, k)  =>  t in [ceil((l-k+1)/stride), floor(l/stride)]
+        int t_hi = l / a.stride;
+        int t_lo = (l - a.k + 1 + a.stride - 1);
+        t_lo = t_lo <= 0 ? 0 : t_lo / a.stride;
+        if (t_hi > a.T - 1) t_hi = a.T - 1;
+        for (int t = t_lo; t <= t_hi; ++t) gsum += a.G[((size_t)b * a.P + t) * a.k + (l - t * a.stride)];
+        if (a.p && a.clamp) {
+            const float u = a.clean[(size_t)b * a.L + l] + pv;
+            if (!(u >= -1.f && u <= 1.f)) gsum = 0.f;           // clamp backward: pass-through inside [-1, 1]
+        }
+        total += gsum;
+    }
+    grad[l] = total;
+}
+
+paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st) {
+    if (a.k > 10 || a.C > 4096) PAA_FAIL(PAA_ERR_ARG, "conv0: kernel %d / channels %d unsupported", a.k, a.C);
+    const int nchunk = cdiv(a.T, C0_TCH);
+    const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10);
+    Conv0Args b = a;
+    b.part = part;
+    hipLaunchKernelGGL(k_conv0_gn<0>, dim3(nchunk, a.B), dim3(256), lds, st, b);
+    PAA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 256)), dim3(256), 0, st, (const float*)part,
+                       (float*)a.gn_stats, a.B, a.C, nchunk, a.T, a.eps, 0);
+    PAA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_conv0_gn<1>, dim3(nchunk, a.B), dim3(256), lds, st, b);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+paa_status conv0_ln_forward(const Conv0Args& a, hipStream_t st) {
+    if (a.k > 10 || a.C > 512) PAA_FAIL(PAA_ERR_ARG, "conv0(layer): kernel %d / channels %d unsupported", a.k, a.C);
+    hipLaunchKernelGGL(k_conv0_rows<C0_FWD_LN>, dim3(std::min(cdiv(a.P, 4), 512), a.B), dim3(256), 0, st, a);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+paa_status conv0_backward(const Conv0Args& a, int layer_norm, float* part, float* grad, hipStream_t st) {
+    if (a.k > 10 || a.C > 512) PAA_FAIL(PAA_ERR_ARG, "conv0 backward: kernel %d / channels %d unsupported", a.k, a.C);
+    if (layer_norm) {
+        hipLaunchKernelGGL(k_conv0_rows<C0_BWD_LN>, dim3(std::min(cdiv(a.P, 4), 512), a.B), dim3(256), 0, st, a);
+        PAA_LAUNCH_CHECK();
+    } else {
+        const int nchunk = cdiv(a.T, C0_TCH);
+        const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10);
+        Conv0Args b = a;
+        b.part = part;
+        hipLaunchKernelGGL(k_conv0_gn<2>, dim3(nchunk, a.B), dim3(256), lds, st, b);
+        PAA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 256)), dim3(256), 0, st, (const float*)part,
+                           (float*)a.gn_bsums, a.B, a.C, nchunk, a.T, a.eps, 2);
+        PAA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_conv0_rows<C0_BWD_GN>, dim3(std::min(cdiv(a.P, 4), 512), a.B), dim3(256), 0, st, a);
+        PAA_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_input_grad, dim3(cdiv(a.L, 256)), dim3(256), 0, st, a, grad);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+// ===================================================================================== CTC ===
+// One workgroup per clip.  Phase 1: log-softmax of every frame (32 lanes per frame) -> lp[T][V].
+// Phase 2: alpha over the extended label sequence l' (blank, l1, blank, ..., blank), previous row in
+// LDS, every row stored for phase 3.  Phase 3: beta backwards; the posterior occupancy
+// gamma_t(s) = exp(alpha + beta + nll - lp) is summed per class with fixed-point LDS atomics (order
+// independent => bitwise reproducible) and dlogits[t][c] = scale * (softmax[t][c] - occ[c]).
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + log1pf(__expf(-fabsf(a - b)));   // the larger term contributes exp(0) = 1
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+__global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                           int T, int Tpad, int V, int S_max, int blank, float gscale,
+                                           float* __restrict__ nll_out, float* __restrict__ dlogits,
+                                           float* __restrict__ work, int64_t work_per_clip) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int SPmax = 2 * S_max + 1;
+    float* prev = sm;                       // [SPmax]
+    float* cur = sm + SPmax;                // [SPmax]
+    int* lab = reinterpret_cast<int*>(sm + 2 * SPmax);   // [SPmax] extended labels
+    unsigned* occ = reinterpret_cast<unsigned*>(sm + 3 * SPmax);   // [V]
+    __shared__ int s_len;
+    __shared__ float s_nll;
+
+    const float* lg = logits + (size_t)b * Tpad * V;
+    float* lp = work + (size_t)b * work_per_clip;            // [T][V]
+    float* alpha = lp + (size_t)T * V;                       // [T][SPmax]
+
+    if (tid == 0) {
+        int n = 0;
+        for (int s = 0; s < S_max; ++s) if (labels[(size_t)b * S_max + s] >= 0) ++n;
+        s_len = n;
+    }
+    // phase 1: log-softmax (float32), 32 lanes per frame
+    for (int t = tid >> 5; t < T; t += 8) {
+        const int c = tid & 31;
+        float mx = -INFINITY;
+        for (int cc = c; cc < V; cc += 32) mx = fmaxf(mx, lg[(size_t)t * V + cc]);
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
+        float se = 0.f;
+        for (int cc = c; cc < V; cc += 32) se += expf(lg[(size_t)t * V + cc] - mx);
+        for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 32);
+        const float lz = mx + logf(se);
+        for (int cc = c; cc < V; cc += 32) lp[(size_t)t * V + cc] = lg[(size_t)t * V + cc] - lz;
+    }
+    __syncthreads();
+    const int S = s_len;
+    const int SP = 2 * S + 1;
+    // extended labels: valid labels are the non-negative entries, in order (HF masked_select)
+    if (tid == 0) {
+        int k = 0;
+        lab[0] = blank;
+        for (int s = 0; s < S_max; ++s) {
+            const int v = labels[(size_t)b * S_max + s];
+            if (v >= 0) { lab[2 * k + 1] = v; lab[2 * k + 2] = blank; ++k; }
+        }
+    }
+    __syncthreads();
+    // phase 2: alpha
+    for (int s = tid; s < SP; s += 256) {
+        float v = -INFINITY;
+        if (s == 0) v = lp[blank];
+        else if (s == 1) v = lp[lab[1]];
+        prev[s] = v;
+        alpha[s] = v;
+    }
+    __syncthreads();
+    for (int t = 1; t < T; ++t) {
+        for (int s = tid; s < SP; s += 256) {
+            const int l = lab[s];
+            const float a0 = prev[s];
+            const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+            const float a2 = (s >= 2 && l != blank && l != lab[s - 2]) ? prev[s - 2] : -INFINITY;
+            const float v = lse3(a0, a1, a2) + lp[(size_t)t * V + l];
+            cur[s] = v;
+            alpha[(size_t)t * SPmax + s] = v;
+        }
+        __syncthreads();
+        float* tmp = prev; prev = cur; cur = tmp;
+    }
+    if (tid == 0) {
+        const float l1 = prev[SP - 1];
+        const float l2 = SP >= 2 ? prev[SP - 2] : -INFINITY;
+        const float nll = -lse2(l1, l2);
+        s_nll = nll;
+        nll_out[b] = nll;
+    }
+    __syncthreads();
+    if (!dlogits) return;
+    const float nll = s_nll;
+    float* dl = dlogits + (size_t)b * Tpad * V;
+    for (int i = tid; i < (Tpad - T) * V; i += 256) dl[(size_t)T * V + i] = 0.f;     // pad frames
+    if (!(nll < INFINITY)) {      // infeasible alignment: zero_infinity=False propagates non-finite gradients
+        for (int i = tid; i < T * V; i += 256) dl[i] = NAN;
+        return;
+    }
+    // phase 3: beta + gradient.  beta_{T-1}: last blank and last label.
+    for (int s = tid; s < SP; s += 256) {
+        float v = -INFINITY;
+        if (s == SP - 1 || s == SP - 2) v = lp[(size_t)(T - 1) * V + lab[s]];
+        prev[s] = v;
+    }
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        if (t < T - 1) {
+            for (int s = tid; s < SP; s += 256) {
+                const int l = lab[s];
+                const float b0 = prev[s];
+                const float b1 = s + 1 < SP ? prev[s + 1] : -INFINITY;
+                const float b2 = (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l) ? prev[s + 2] : -INFINITY;
+                cur[s] = lse3(b0, b1, b2) + lp[(size_t)t * V + l];
+            }
+            __syncthreads();
+            float* tmp = prev; prev = cur; cur = tmp;
+        }
+        for (int c = tid; c < V; c += 256) occ[c] = 0u;
+        __syncthreads();
+        for (int s = tid; s < SP; s += 256) {
+            const int l = lab[s];
+            const float g = __expf(alpha[(size_t)t * SPmax + s] + prev[s] + nll - lp[(size_t)t * V + l]);
+            const unsigned q = (unsigned)(fminf(g, 2.f) * 1073741824.f + 0.5f);
+            if (q) atomicAdd(&occ[l], q);
+        }
+        __syncthreads();
+        for (int c = tid; c < V; c += 256)
+            dl[(size_t)t * V + c] = gscale * (__expf(lp[(size_t)t * V + c]) - (float)occ[c] * (1.f / 1073741824.f));
+        __syncthreads();
+    }
+}
+
+int conv0_chunks(int T) { return cdiv(T, C0_TCH); }
+
+int64_t ctc_work_floats_per_clip(int T, int V, int S_max) { return (int64_t)T * V + (int64_t)T * (2 * S_max + 1); }
+
+paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
+               float grad_scale, float* nll, float* dlogits, float* work, hipStream_t st) {
+    if (S_max < 1 || S_max > 4000) PAA_FAIL(PAA_ERR_SIZE, "ctc: S_max=%d out of range", S_max);
+    if (V > 256) PAA_FAIL(PAA_ERR_SIZE, "ctc: vocab %d > 256", V);
+    const int SPmax = 2 * S_max + 1;
+    const size_t lds = sizeof(float) * (3 * (size_t)SPmax + V);
+    hipLaunchKernelGGL(k_ctc, dim3(B), dim3(256), lds, st, logits, labels, T, Tpad, V, S_max, blank, grad_scale, nll,
+                       dlogits, work, ctc_work_floats_per_clip(T, V, S_max));
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+__global__ void k_sum_small(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ double red[256 / 64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+    s = block_sum<double, 256>(s, red);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+paa_status sum_small(const float* x, int n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(256), 0, st, x, n, out);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+}  // namespace paa
+
+using namespace paa;
+
+extern "C" paa_status paa_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats,
+                                        int rows, int cols, float eps, void* stream) {
+    return layernorm_fwd(x, g, b, y, stats, rows, cols, eps, nullptr, (hipStream_t)stream);
+}
+extern "C" paa_status paa_layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, float* dx,
+                                        int rows, int cols, void* stream) {
+    return layernorm_bwd(dy, x, g, stats, nullptr, nullptr, dx, rows, cols, (hipStream_t)stream);
+}
+extern "C" paa_status paa_softmax_fwd(float* s, int rows, int cols, int ld, float scale, void* stream) {
+    return softmax_fwd(s, 1, rows, rows, cols, ld, scale, (hipStream_t)stream);
+}
+extern "C" paa_status paa_softmax_bwd(float* dp, const float* p, int rows, int cols, int ld, float scale, void* stream) {
+    return softmax_bwd(dp, p, 1, rows, rows, cols, ld, scale, (hipStream_t)stream);
+}
+extern "C" int64_t paa_ctc_work_floats(int B, int T, int V, int S_max) { return (int64_t)B * ctc_work_floats_per_clip(T, V, S_max); }
+extern "C" paa_status paa_ctc(const float* logits, const int32_t* labels, int B, int T, int V, int S_max, int blank,
+                              float grad_scale, float* nll, float* dlogits, float* work, void* stream) {
+    return ctc(logits, labels, B, T, T, V, S_max, blank, grad_scale, nll, dlogits, work, (hipStream_t)stream);
+}

@@ -1,0 +1,79 @@
+// Shared host/device helpers for libpaa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/paa_hip.h"
+
+namespace paa {
+
+void set_error(const std::string& msg);
+
+#define PAA_FAIL(code, ...)                                  \
+    do {                                                     \
+        char _b[512];                                        \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);               \
+        ::paa::set_error(_b);                                \
+        return (code);                                       \
+    } while (0)
+
+#define PAA_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) PAA_FAIL(PAA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define PAA_LAUNCH_CHECK()                                                                            \
+    do {                                                                                              \
+        hipError_t _e = hipGetLastError();                                                            \
+        if (_e != hipSuccess) PAA_FAIL(PAA_ERR_HIP, "kernel launch (%s:%d): %s", __FILE__, __LINE__, \
+                                       hipGetErrorString(_e));                                        \
+    } while (0)
+
+#define PAA_TRY(expr)                      \
+    do {                                   \
+        paa_status _s = (expr);            \
+        if (_s != PAA_OK) return _s;       \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- wave (64 lanes) / block reductions --------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in every thread.
+// `sm` must hold NT/64 elements of T; the caller must not reuse it before the next barrier.
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    T r = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += sm[i];
+    __syncthreads();
+    return r;
+}
+
+// exact (erf) GELU and its derivative, as torch.nn.functional.gelu(approximate='none')
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+}  // namespace paa

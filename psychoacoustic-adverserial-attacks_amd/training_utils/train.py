@@ -1,0 +1,97 @@
+"""Same call surface as the reference's ``src/training_utils/train.py``:
+``perturbation_constraint(p, clean_audio, args, interp, spl_thresh)`` and
+``train_epoch(args, train_data_loader, p, model, epoch, processor, interp, wer_metric, spl_thresh, optimizer)``
+— executed by libpaa_hip.so."""
+from __future__ import annotations
+
+import logging
+import time
+from dataclasses import dataclass
+from typing import Iterable
+
+import torch
+
+from .. import _lib, runtime
+from ..core import loss_helpers
+from .pgd import FREQ_NORMS, PgdStepper
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass(frozen=True)
+class TrainEpochResult:          # train.py:15-19
+    p: torch.Tensor
+    avg_ctc: float
+    avg_wer: float
+
+
+def _avg(values: Iterable[float]) -> float:
+    vals = list(values)
+    return sum(vals) / max(len(vals), 1)
+
+
+def perturbation_constraint(p: torch.Tensor, clean_audio, args, interp, spl_thresh) -> torch.Tensor:
+    """train.py:69-99.  Returns a new tensor; ``p`` is left untouched.  ``args.norm_type`` may be a
+    '+'-joined list (extension, applied in the written order)."""
+    norms = str(args.norm_type).split("+")
+    for n in norms:
+        if n not in _lib.NORM_IDS:
+            raise ValueError(f"Unknown norm_type: {n!r}")                                   # train.py:98
+        if n == "snr" and clean_audio is None:
+            raise ValueError("SNR projection requires clean_audio ro compare to")           # train.py:91
+        if n == "tv" and clean_audio is None:
+            raise ValueError("TV projection can benefit from clean_audio for bounds")       # train.py:95
+    q = runtime.as_f32_cuda(p.detach(), "p").clone()
+    rows, L = (q.shape[0], q.shape[1]) if q.dim() == 2 else (1, q.shape[0])
+    clean = None if clean_audio is None else runtime.as_f32_cuda(clean_audio, "clean_audio")
+    if clean is not None and clean.shape[-1] != L:
+        raise ValueError(f"clean_audio length {clean.shape[-1]} != perturbation length {L}")
+    pr = runtime.get_proj(args, q.device, rows, L, interp)
+    out_len = L
+    with torch.cuda.device(q.device):
+        for n in norms:
+            a = type("A", (), dict(vars(args)))()
+            a.norm_type = n
+            if n == "max_phon":
+                pr.set_spl_thresh(spl_thresh)
+            _lib.check(_lib.lib().paa_project(pr.h, runtime.params_of(a), _lib.ptr(q), rows, _lib.ptr(clean),
+                                              0 if clean is None else clean.shape[0], L, _lib.stream_ptr()))
+            if n in FREQ_NORMS and clean is None:
+                out_len = pr.hop * (L // pr.hop)        # iSTFT length hop*(T-1); no _align_to without clean audio
+    return q if out_len == L else q[..., :out_len]
+
+
+def train_epoch(args, train_data_loader, p: torch.Tensor, model, epoch: int, processor, interp, wer_metric,
+                spl_thresh, optimizer) -> TrainEpochResult:
+    """train.py:103-182.  ``model`` is a ``paa_amd.model.PaaModel``."""
+    ctc_scores, wer_scores, times = [], [], []
+    logger.info("starting epoch: %d", epoch)
+    if args.optimizer_type not in ("pgd", "adam"):
+        raise NotImplementedError(f"Optimization type not implemented: {args.optimizer_type!r}")   # train.py:177
+    if args.optimizer_type == "adam" and optimizer is None:
+        raise ValueError("Adam optimizer selected but optimizer is None")                          # train.py:167
+    L = p.shape[-1]
+    stepper = getattr(model, "_stepper", None)
+    if stepper is None or stepper.args is not args or stepper.L != L:
+        stepper = PgdStepper(model, args, L, interp, spl_thresh)
+        model._stepper = stepper
+    for clean_audio, target_texts in train_data_loader:
+        t0 = time.perf_counter()
+        clean_audio = clean_audio.to(args.device, non_blocking=True)                # train.py:129
+        labels = loss_helpers.make_labels(target_texts, processor, args, len(clean_audio))
+        if args.optimizer_type == "pgd":
+            if isinstance(p, torch.nn.Parameter) or p.requires_grad:
+                p = p.detach()
+            r = stepper.step(p, clean_audio, labels)
+        else:
+            r = model.fwd_bwd(clean_audio, p.data, labels, stepper.direction)
+            optimizer.zero_grad(set_to_none=True)
+            p.grad = -r["grad"].view_as(p)          # gradient of (-direction * loss), train.py:170
+            optimizer.step()
+            with torch.no_grad():
+                p.data = perturbation_constraint(p.data, clean_audio, args, interp, spl_thresh)   # train.py:172-175
+        ctc_scores.append(float(r["loss"].item()))                                   # train.py:146
+        wer = loss_helpers.compute_wer(r["logits"], target_texts, processor, wer_metric)   # train.py:149-153
+        wer_scores.append(float(wer))
+        times.append(time.perf_counter() - t0)
+    return TrainEpochResult(p=p, avg_ctc=_avg(ctc_scores), avg_wer=_avg(wer_scores))

@@ -1,0 +1,177 @@
+"""-m gpu: each HIP kernel against a float64 / torch-fp32 statement of the same op, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gemm_ref import emulate
+from gpu_util import dev, rel_err, run_gemm
+from paa_amd import _lib
+
+pytestmark = pytest.mark.gpu
+TOL = {0: 1.5e-2, 1: 6e-5}      # bf16 operands | split-bf16 (fp32-parity) — relative to max|ref|
+
+
+def _case(name, d, shapes, prec, seed=0, offs=None, zero_c=False):
+    """shapes: operand name -> flat length.  Runs HIP and the numpy emulator on identical buffers."""
+    rng = np.random.default_rng(seed)
+    host = {k: rng.normal(size=n).astype(np.float32) for k, n in shapes.items()}
+    if zero_c:
+        host["C"][:] = 0
+    bufs = {k: dev(v) for k, v in host.items()}
+    dd = dict(d)
+    dd["precision"] = prec
+    names = {k: k for k in shapes}
+    run_gemm({**dd, **names}, bufs, offs)
+    ref = {k: v.astype(np.float64) for k, v in host.items()}
+    o = offs or {}
+    emulate(dd, ref["A"], ref["B"], ref["C"], a_off=o.get("A", 0), b_off=o.get("B", 0), c_off=o.get("C", 0),
+            bias=ref.get("bias"), aux=ref.get("aux"), aux_off=o.get("aux", 0), residual=ref.get("residual"),
+            res_off=o.get("residual", 0), C_pre=ref.get("C_pre"))
+    e = rel_err(bufs["C"].cpu().numpy(), ref["C"])
+    print(f"gemm[{name}] prec={prec} rel_err={e:.3e}")
+    assert e < TOL[prec], name
+    if "C_pre" in shapes:
+        e2 = rel_err(bufs["C_pre"].cpu().numpy(), ref["C_pre"])
+        print(f"gemm[{name}] C_pre rel_err={e2:.3e}")
+        assert e2 < TOL[prec], name + ".C_pre"
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_plain_edges_bias_gelu(prec):
+    M, N, K = 300, 200, 96
+    _case("plain", dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, act=1), dict(A=M * K, B=N * K, C=M * N, bias=N, C_pre=M * N), prec)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_big_k(prec):
+    M, N, K = 257, 384, 1536
+    _case("bigk", dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N), dict(A=M * K, B=N * K, C=M * N), prec)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_conv_view_rowmask(prec):
+    Cc, k, s, M = 32, 3, 2, 250
+    rows = s * M + 8
+    _case("convview", dict(M=M, N=Cc, K=k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Cc, row_period=50, row_valid=49, act=1),
+          dict(A=rows * Cc, B=Cc * k * Cc, C=M * Cc, C_pre=M * Cc), prec)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_k_tail_and_narrow(prec):
+    M, N, K = 130, 48, 499
+    _case("ktail", dict(M=M, N=N, K=K, lda=512, ldb=512, ldc=N), dict(A=M * 512, B=N * 512, C=M * N), prec)
+    _case("n32", dict(M=200, N=32, K=64, lda=64, ldb=64, ldc=32), dict(A=200 * 64, B=32 * 64, C=200 * 32, bias=32), prec)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_transposed_operands(prec):
+    T, hd, ld = 499, 64, 512
+    # P V : A (T x T, ld 512) k-contig, B [K][N] with ldb 192
+    _case("pv", dict(M=T, N=hd, K=T, lda=ld, ldb=192, b_kcontig=0, ldc=hd), dict(A=T * ld, B=T * 192, C=T * hd), prec)
+    # P^T dO : A stored [K][M], B [K][N]
+    _case("ptdo", dict(M=T, N=hd, K=T, lda=ld, a_kcontig=0, ldb=64, b_kcontig=0, ldc=192),
+          dict(A=T * ld, B=T * 64, C=T * 192), prec, zero_c=True)
+    # A^T with B k-contig
+    _case("at_b", dict(M=100, N=130, K=72, lda=104, a_kcontig=0, ldb=72, ldc=130), dict(A=72 * 104, B=130 * 72, C=100 * 130), prec)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_batched_heads(prec):
+    B, nh, T, hd, P = 2, 3, 70, 16, 71
+    H3 = 3 * nh * hd
+    Tp = 96
+    d = dict(M=T, N=T, K=hd, lda=H3, ldb=H3, ldc=Tp, batch=B * nh, batch2=nh, a_s1=P * H3, a_s2=hd, b_s1=P * H3, b_s2=hd,
+             c_s1=nh * Tp * Tp, c_s2=Tp * Tp)
+    _case("qk", d, dict(A=B * P * H3, B=B * P * H3, C=B * nh * Tp * Tp), prec, offs=dict(B=nh * hd), zero_c=True)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_window_segment(prec):
+    B, G, Hg, Kt, T, P = 2, 4, 16, 16, 40, 41
+    H = G * Hg
+    d = dict(M=T, N=Hg, K=Kt * Hg, lda=H, ldb=Kt * Hg, ldc=H, a_kseg=Hg, a_kseg_stride=H, a_window=1, a_pad=Kt // 2,
+             a_rows_valid=T, batch=B * G, batch2=G, a_s1=P * H, a_s2=Hg, b_s2=Hg * Kt * Hg, c_s1=P * H, c_s2=Hg,
+             bias_s2=Hg, act=1, ld_res=H, res_s1=P * H, res_s2=Hg)
+    _case("window", d, dict(A=B * P * H, B=G * Hg * Kt * Hg, C=B * P * H, bias=H, C_pre=B * P * H, residual=B * P * H), prec,
+          zero_c=True)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_gelu_grad_residual_accumulate(prec):
+    M, N, K = 140, 96, 64
+    _case("gelugrad", dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=2 * N, act=2, ld_aux=2 * N, ld_res=N, accumulate=1),
+          dict(A=M * K, B=N * K, C=M * 2 * N, aux=M * 2 * N, residual=M * N), prec, offs=dict(C=N, aux=N))
+
+
+def test_layernorm_fwd_bwd():
+    torch.manual_seed(0)
+    for rows, cols in ((37, 512), (130, 768), (9, 64), (5, 32)):
+        x = torch.randn(rows, cols) * 2 + 0.3
+        g = torch.randn(cols) * 0.1 + 1
+        b = torch.randn(cols) * 0.1
+        dy = torch.randn(rows, cols)
+        xr = x.clone().requires_grad_(True)
+        yr = F.layer_norm(xr, (cols,), g, b, eps=1e-5)
+        yr.backward(dy)
+        xd, gd, bd, dyd = x.cuda(), g.cuda(), b.cuda(), dy.cuda()
+        y = torch.empty_like(xd); st = torch.empty(rows, 2, device="cuda"); dx = torch.empty_like(xd)
+        L = _lib.lib()
+        _lib.check(L.paa_layernorm_fwd(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(y), _lib.ptr(st), rows, cols, 1e-5, _lib.stream_ptr()))
+        _lib.check(L.paa_layernorm_bwd(_lib.ptr(dyd), _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(st), _lib.ptr(dx), rows, cols, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        e1, e2 = rel_err(y.cpu(), yr.detach()), rel_err(dx.cpu(), xr.grad)
+        print(f"layernorm {rows}x{cols}: fwd {e1:.2e} bwd {e2:.2e}")
+        assert e1 < 1e-5 and e2 < 2e-5
+
+
+def test_softmax_fwd_bwd():
+    torch.manual_seed(1)
+    rows, cols, ld = 77, 499, 512
+    s = torch.randn(rows, ld) * 3
+    dp = torch.randn(rows, ld)
+    sr = s[:, :cols].clone().requires_grad_(True)
+    pr = torch.softmax(sr * 0.125, -1)
+    pr.backward(dp[:, :cols])
+    sd, dpd = s.cuda(), dp.cuda()
+    L = _lib.lib()
+    _lib.check(L.paa_softmax_fwd(_lib.ptr(sd), rows, cols, ld, 0.125, _lib.stream_ptr()))
+    _lib.check(L.paa_softmax_bwd(_lib.ptr(dpd), _lib.ptr(sd), rows, cols, ld, 0.125, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(sd.cpu()[:, :cols], pr.detach()), rel_err(dpd.cpu()[:, :cols], sr.grad)
+    print(f"softmax fwd {e1:.2e} bwd {e2:.2e}")
+    assert e1 < 1e-5 and e2 < 2e-5
+    assert float(sd[:, cols:].abs().max()) == 0 and float(dpd[:, cols:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("T,S_max,lens", [(24, 6, [5, 6, 3, 0]), (499, 150, [150, 120, 1, 77]), (60, 30, [30, 29, 30, 2])])
+def test_ctc(T, S_max, lens):
+    torch.manual_seed(2)
+    B, V = len(lens), 32
+    logits = torch.randn(B, T, V) * 2
+    labels = torch.full((B, S_max), -100, dtype=torch.long)
+    for b, n in enumerate(lens):
+        labels[b, :n] = torch.randint(1, V, (n,))
+        if n > 3:
+            labels[b, 2] = labels[b, 1]            # a repeated label forces the blank transition rule
+    lr = logits.clone().requires_grad_(True)
+    lp = F.log_softmax(lr, -1).transpose(0, 1)
+    mask = labels >= 0
+    nll = F.ctc_loss(lp, labels.masked_select(mask), torch.full((B,), T), mask.sum(-1), blank=0, reduction="none",
+                     zero_infinity=False)
+    nll.sum().backward()
+    lg, lab = logits.cuda(), labels.to(torch.int32).cuda()
+    out_nll = torch.empty(B, device="cuda"); dl = torch.empty_like(lg)
+    L = _lib.lib()
+    work = torch.empty(L.paa_ctc_work_floats(B, T, V, S_max), device="cuda")
+    _lib.check(L.paa_ctc(_lib.ptr(lg), _lib.ptr(lab), B, T, V, S_max, 0, 1.0, _lib.ptr(out_nll), _lib.ptr(dl), _lib.ptr(work), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    fin = torch.isfinite(nll)
+    print("ctc nll", out_nll.cpu().tolist(), nll.tolist())
+    assert torch.equal(torch.isfinite(out_nll.cpu()), fin)
+    e1 = rel_err(out_nll.cpu()[fin], nll.detach()[fin])
+    e2 = rel_err(dl.cpu()[fin], lr.grad[fin])
+    print(f"ctc T={T}: nll {e1:.2e} grad {e2:.2e}")
+    assert e1 < 2e-6 and e2 < 5e-5

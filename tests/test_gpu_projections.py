@@ -1,0 +1,98 @@
+"""-m gpu: the HIP projection path against (a) the goldens produced by the reference itself and
+(b) the oracle at BASELINE sizes, plus size-independent properties (idempotence, STFT round trip)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import rel_err
+from oracle import projections as OP
+from oracle.gen_cases import AMPS, LENGTHS, NORM_CASES, case_name, cli_to_args
+from paa_amd import synth
+from paa_amd.core import fourier_transforms, projections
+from paa_amd.training_utils import build, train
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5      # |got - ref| <= TOL * max|ref|  (fp32 FFT / reduction-order differences)
+
+
+def _args(norm, extra):
+    a = cli_to_args(norm, extra)
+    a.device = "cuda"
+    return a
+
+
+@pytest.mark.parametrize("norm,extra", NORM_CASES)
+def test_constraint_vs_reference_goldens(gold, norm, extra):
+    g = gold("projections.npz")
+    args = _args(norm, extra)
+    spl = build.init_phon_threshold_tensor(args)
+    worst = 0.0
+    for L in LENGTHS + [16000]:
+        for B in ([1, 3] if norm in ("snr", "tv") else [1]):
+            for amp in AMPS:
+                clean = torch.from_numpy(synth.clean_audio(B, L)).cuda()
+                p = torch.from_numpy(synth.perturbation(L) * np.float32(amp)).cuda()
+                q = train.perturbation_constraint(p, clean, args, None, spl).cpu().numpy()
+                name = case_name(norm, extra, L, B, amp)
+                ref, got = (g[name + "|samples"], q[0, ::7]) if L == 16000 else (g[name], q)
+                e = rel_err(got, ref) if np.abs(ref).max() > 0 else float(np.abs(got).max())
+                worst = max(worst, e)
+                assert e <= TOL, (name, e)
+    print(f"{norm} {extra}: worst rel err {worst:.2e}")
+
+
+def test_stft_istft_vs_goldens(gold):
+    g = gold("projections.npz")
+    args = _args("max_phon", [])
+    for L in (4096, 5000):
+        p = torch.from_numpy(np.concatenate([synth.perturbation(L) * np.float32(1e-2), synth.clean_audio(1, L)], 0)).cuda()
+        S = fourier_transforms.compute_stft(p, args)
+        ref = torch.view_as_complex(torch.from_numpy(g[f"stft|L{L}"]))
+        assert tuple(S.shape) == tuple(ref.shape)
+        e = float((S.cpu() - ref).abs().max() / ref.abs().max())
+        y = fourier_transforms.compute_istft(ref.cuda(), args).cpu().numpy()
+        e2 = float(np.abs(y - g[f"istft|L{L}"]).max())
+        print(f"stft L={L}: rel {e:.2e}; istft abs {e2:.2e}")
+        assert e < 5e-6 and e2 < 5e-7
+
+
+@pytest.mark.parametrize("norm,extra", [("snr", ["--snr_db", "40"]), ("tv", []), ("l2", []), ("linf", []),
+                                        ("fletcher_munson", ["--fm_epsilon", "2.0"]), ("max_phon", []), ("min_max_freqs", [])])
+def test_constraint_full_size_vs_oracle(norm, extra):
+    """BASELINE size: (1, 160000) perturbation, batch of 10 s clips."""
+    args = _args(norm, extra)
+    L, B = 160000, 4
+    clean = torch.from_numpy(synth.clean_audio(B, L))
+    for amp in (1e-3, 0.2):
+        p = torch.from_numpy(synth.perturbation(L) * np.float32(amp))
+        ref = OP.perturbation_constraint(p, clean, args, OP.spl_thresh_tensor(args)).numpy()
+        spl = build.init_phon_threshold_tensor(args)
+        got = train.perturbation_constraint(p.cuda(), clean.cuda(), args, None, spl)
+        e = rel_err(got.cpu().numpy(), ref)
+        print(f"{norm} amp={amp}: rel err {e:.2e}")
+        assert e <= TOL
+        # idempotence of the feasible-set projections (scale-type norms and linf): projecting twice changes nothing more
+        if norm in ("l2", "linf", "tv"):
+            again = train.perturbation_constraint(got, clean.cuda(), args, None, spl)
+            assert rel_err(again.cpu().numpy(), got.cpu().numpy()) <= 2e-6
+
+
+def test_batched_rows_and_errors():
+    args = _args("l2", [])
+    x = torch.from_numpy(synth.clean_audio(4, 8192)).cuda()
+    q = projections.project_l2(x, 0.05)
+    assert abs(float(q.norm()) - 0.05) < 1e-6
+    with pytest.raises(ValueError):
+        train.perturbation_constraint(x[:1], None, _args("snr", []), None, None)
+    with pytest.raises(ValueError):
+        train.perturbation_constraint(x[:1], None, _args("tv", []), None, None)
+    bad = types.SimpleNamespace(**vars(args)); bad.norm_type = "l1"
+    with pytest.raises(ValueError):
+        train.perturbation_constraint(x[:1], x, bad, None, None)
+    # STFT -> iSTFT round trip at full length (size-independent property)
+    a2 = _args("max_phon", [])
+    p = torch.from_numpy(synth.perturbation(160000) * np.float32(1e-2)).cuda()
+    y = fourier_transforms.compute_istft(fourier_transforms.compute_stft(p, a2), a2)
+    assert float((y - p[:, : y.shape[1]]).abs().max()) < 2e-8 * 100
