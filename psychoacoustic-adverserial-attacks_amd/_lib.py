@@ -75,6 +75,8 @@ _SIGS = {
     "paa_model_debug_read": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int]),
     "paa_model_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "paa_gemm": (C.c_int, [C.POINTER(PaaGemmDesc), C.c_void_p]),
+    "paa_prof_enable": (C.c_int, [C.c_int]),
+    "paa_prof_read": (C.c_int, [C.c_void_p]),
     "paa_layernorm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "paa_layernorm_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p]),
     "paa_softmax_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),

@@ -11,6 +11,7 @@
 // segmented K with a zero-filled time window (the grouped positional convolution), and the
 // M-/N-contiguous (transposed) operands of the attention backward products.
 #include <algorithm>
+#include <vector>
 
 #include "gemm.h"
 #include "paa_common.h"
@@ -256,6 +257,16 @@ static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((k_gemm<BN, PREC, false, false>), grid, dim3(G_NT), 0, st, g);
 }
 
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream ----------
+struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<double> flops;
+    std::vector<int> variant;
+    size_t n = 0, cap = 0;
+};
+static GemmProf g_prof;
+
 paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     if (!d.A || !d.B || !d.C) PAA_FAIL(PAA_ERR_ARG, "gemm: null operand");
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0 || d.batch2 <= 0) PAA_FAIL(PAA_ERR_SIZE, "gemm: bad dims %d %d %d", d.M, d.N, d.K);
@@ -272,13 +283,52 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     g.tiles_m = cdiv(d.M, G_BM);
     g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
+    const bool prof = g_prof.on && g_prof.n < g_prof.cap;
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+        g_prof.flops[g_prof.n] = 2.0 * d.M * d.N * (double)d.K * d.batch;
+        g_prof.variant[g_prof.n] = (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
+    }
     if (narrow) { if (d.precision) launch_gemm<64, 1>(g, grid, st); else launch_gemm<64, 0>(g, grid, st); }
     else { if (d.precision) launch_gemm<128, 1>(g, grid, st); else launch_gemm<128, 0>(g, grid, st); }
+    if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
 
 }  // namespace paa
+
+// Enable (max_launches > 0) or disable (0) event timing of every GEMM launch.  Not capturable.
+extern "C" paa_status paa_prof_enable(int max_launches) {
+    using namespace paa;
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear(); g_prof.n = 0; g_prof.cap = 0; g_prof.on = false;
+    if (max_launches <= 0) return PAA_OK;
+    g_prof.ev.resize(2 * (size_t)max_launches);
+    for (auto& e : g_prof.ev) PAA_HIP(hipEventCreate(&e));
+    g_prof.flops.assign(max_launches, 0.0);
+    g_prof.variant.assign(max_launches, 0);
+    g_prof.cap = max_launches; g_prof.on = true;
+    return PAA_OK;
+}
+
+// out[16][3] = per kernel variant (narrow*8 + split*4 + a_kcontig*2 + b_kcontig): launches, total ms, total FLOP.
+// Synchronises on the last recorded event.  Resets the counters.
+extern "C" paa_status paa_prof_read(double* out48) {
+    using namespace paa;
+    if (!out48) PAA_FAIL(PAA_ERR_ARG, "paa_prof_read: null");
+    for (int i = 0; i < 48; ++i) out48[i] = 0.0;
+    if (g_prof.n == 0) return PAA_OK;
+    PAA_HIP(hipEventSynchronize(g_prof.ev[2 * g_prof.n - 1]));
+    for (size_t i = 0; i < g_prof.n; ++i) {
+        float ms = 0.f;
+        PAA_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        const int v = g_prof.variant[i];
+        out48[3 * v] += 1.0; out48[3 * v + 1] += ms; out48[3 * v + 2] += g_prof.flops[i];
+    }
+    g_prof.n = 0;
+    return PAA_OK;
+}
 
 extern "C" paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream) {
     if (!d) { paa::set_error("paa_gemm: null descriptor"); return PAA_ERR_ARG; }

@@ -425,51 +425,55 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, float* part, float
 // LDS, every row stored for phase 3.  Phase 3: beta backwards; the posterior occupancy
 // gamma_t(s) = exp(alpha + beta + nll - lp) is summed per class with fixed-point LDS atomics (order
 // independent => bitwise reproducible) and dlogits[t][c] = scale * (softmax[t][c] - occ[c]).
-__device__ __forceinline__ float lse2(float a, float b) {
-    const float m = fmaxf(a, b);
+// The recursions run in float64: alpha + beta + nll cancels numbers of magnitude ~1e3, which in float32
+// (as torch's CPU kernel computes it) leaves ~1e-3 relative noise in the gradient; the work is tiny
+// (B * T * (2S+1) log-sum-exps), so the exact form costs nothing measurable.
+__device__ __forceinline__ double lse2(double a, double b) {
+    const double m = fmax(a, b);
     if (m == -INFINITY) return -INFINITY;
-    return m + log1pf(__expf(-fabsf(a - b)));   // the larger term contributes exp(0) = 1
+    return m + log1p(exp(-fabs(a - b)));
 }
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-    const float m = fmaxf(a, fmaxf(b, c));
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
     if (m == -INFINITY) return -INFINITY;
-    return m + logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
 }
 
 __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                            int T, int Tpad, int V, int S_max, int blank, float gscale,
                                            float* __restrict__ nll_out, float* __restrict__ dlogits,
                                            float* __restrict__ work, int64_t work_per_clip) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    extern __shared__ __attribute__((aligned(16))) double smd[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int SPmax = 2 * S_max + 1;
-    float* prev = sm;                       // [SPmax]
-    float* cur = sm + SPmax;                // [SPmax]
-    int* lab = reinterpret_cast<int*>(sm + 2 * SPmax);   // [SPmax] extended labels
-    unsigned* occ = reinterpret_cast<unsigned*>(sm + 3 * SPmax);   // [V]
+    double* prev = smd;                     // [SPmax]
+    double* cur = smd + SPmax;              // [SPmax]
+    int* lab = reinterpret_cast<int*>(smd + 2 * SPmax);   // [SPmax] extended labels
+    unsigned* occ = reinterpret_cast<unsigned*>(lab + SPmax);   // [V]
     __shared__ int s_len;
-    __shared__ float s_nll;
+    __shared__ double s_nll;
 
     const float* lg = logits + (size_t)b * Tpad * V;
-    float* lp = work + (size_t)b * work_per_clip;            // [T][V]
-    float* alpha = lp + (size_t)T * V;                       // [T][SPmax]
+    double* wk = reinterpret_cast<double*>(work) + (size_t)b * work_per_clip;
+    double* lp = wk;                                         // [T][V]
+    double* alpha = lp + (size_t)T * V;                      // [T][SPmax]
 
     if (tid == 0) {
         int n = 0;
         for (int s = 0; s < S_max; ++s) if (labels[(size_t)b * S_max + s] >= 0) ++n;
         s_len = n;
     }
-    // phase 1: log-softmax (float32), 32 lanes per frame
+    // phase 1: log-softmax, 32 lanes per frame
     for (int t = tid >> 5; t < T; t += 8) {
         const int c = tid & 31;
         float mx = -INFINITY;
         for (int cc = c; cc < V; cc += 32) mx = fmaxf(mx, lg[(size_t)t * V + cc]);
         for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
-        float se = 0.f;
-        for (int cc = c; cc < V; cc += 32) se += expf(lg[(size_t)t * V + cc] - mx);
+        double se = 0.0;
+        for (int cc = c; cc < V; cc += 32) se += exp((double)lg[(size_t)t * V + cc] - (double)mx);
         for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 32);
-        const float lz = mx + logf(se);
-        for (int cc = c; cc < V; cc += 32) lp[(size_t)t * V + cc] = lg[(size_t)t * V + cc] - lz;
+        const double lz = (double)mx + log(se);
+        for (int cc = c; cc < V; cc += 32) lp[(size_t)t * V + cc] = (double)lg[(size_t)t * V + cc] - lz;
     }
     __syncthreads();
     const int S = s_len;
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
     __syncthreads();
     // phase 2: alpha
     for (int s = tid; s < SP; s += 256) {
-        float v = -INFINITY;
+        double v = -INFINITY;
         if (s == 0) v = lp[blank];
         else if (s == 1) v = lp[lab[1]];
         prev[s] = v;
@@ -496,26 +500,26 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
     for (int t = 1; t < T; ++t) {
         for (int s = tid; s < SP; s += 256) {
             const int l = lab[s];
-            const float a0 = prev[s];
-            const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
-            const float a2 = (s >= 2 && l != blank && l != lab[s - 2]) ? prev[s - 2] : -INFINITY;
-            const float v = lse3(a0, a1, a2) + lp[(size_t)t * V + l];
+            const double a0 = prev[s];
+            const double a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+            const double a2 = (s >= 2 && l != blank && l != lab[s - 2]) ? prev[s - 2] : -INFINITY;
+            const double v = lse3(a0, a1, a2) + lp[(size_t)t * V + l];
             cur[s] = v;
             alpha[(size_t)t * SPmax + s] = v;
         }
         __syncthreads();
-        float* tmp = prev; prev = cur; cur = tmp;
+        double* tmp = prev; prev = cur; cur = tmp;
     }
     if (tid == 0) {
-        const float l1 = prev[SP - 1];
-        const float l2 = SP >= 2 ? prev[SP - 2] : -INFINITY;
-        const float nll = -lse2(l1, l2);
+        const double l1 = prev[SP - 1];
+        const double l2 = SP >= 2 ? prev[SP - 2] : -INFINITY;
+        const double nll = -lse2(l1, l2);
         s_nll = nll;
-        nll_out[b] = nll;
+        nll_out[b] = (float)nll;
     }
     __syncthreads();
     if (!dlogits) return;
-    const float nll = s_nll;
+    const double nll = s_nll;
     float* dl = dlogits + (size_t)b * Tpad * V;
     for (int i = tid; i < (Tpad - T) * V; i += 256) dl[(size_t)T * V + i] = 0.f;     // pad frames
     if (!(nll < INFINITY)) {      // infeasible alignment: zero_infinity=False propagates non-finite gradients
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
     }
     // phase 3: beta + gradient.  beta_{T-1}: last blank and last label.
     for (int s = tid; s < SP; s += 256) {
-        float v = -INFINITY;
+        double v = -INFINITY;
         if (s == SP - 1 || s == SP - 2) v = lp[(size_t)(T - 1) * V + lab[s]];
         prev[s] = v;
     }
@@ -533,41 +537,43 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
         if (t < T - 1) {
             for (int s = tid; s < SP; s += 256) {
                 const int l = lab[s];
-                const float b0 = prev[s];
-                const float b1 = s + 1 < SP ? prev[s + 1] : -INFINITY;
-                const float b2 = (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l) ? prev[s + 2] : -INFINITY;
+                const double b0 = prev[s];
+                const double b1 = s + 1 < SP ? prev[s + 1] : -INFINITY;
+                const double b2 = (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l) ? prev[s + 2] : -INFINITY;
                 cur[s] = lse3(b0, b1, b2) + lp[(size_t)t * V + l];
             }
             __syncthreads();
-            float* tmp = prev; prev = cur; cur = tmp;
+            double* tmp = prev; prev = cur; cur = tmp;
         }
         for (int c = tid; c < V; c += 256) occ[c] = 0u;
         __syncthreads();
         for (int s = tid; s < SP; s += 256) {
             const int l = lab[s];
-            const float g = __expf(alpha[(size_t)t * SPmax + s] + prev[s] + nll - lp[(size_t)t * V + l]);
-            const unsigned q = (unsigned)(fminf(g, 2.f) * 1073741824.f + 0.5f);
+            const double g = exp(alpha[(size_t)t * SPmax + s] + prev[s] + nll - lp[(size_t)t * V + l]);
+            const unsigned q = (unsigned)(fmin(g, 2.0) * 1073741824.0 + 0.5);
             if (q) atomicAdd(&occ[l], q);
         }
         __syncthreads();
         for (int c = tid; c < V; c += 256)
-            dl[(size_t)t * V + c] = gscale * (__expf(lp[(size_t)t * V + c]) - (float)occ[c] * (1.f / 1073741824.f));
+            dl[(size_t)t * V + c] = gscale * (float)(exp(lp[(size_t)t * V + c]) - (double)occ[c] * (1.0 / 1073741824.0));
         __syncthreads();
     }
 }
 
+// work size in FLOATS per clip (the kernel stores doubles): lp [T][V] + alpha [T][2S+1]
 int conv0_chunks(int T) { return cdiv(T, C0_TCH); }
 
-int64_t ctc_work_floats_per_clip(int T, int V, int S_max) { return (int64_t)T * V + (int64_t)T * (2 * S_max + 1); }
+int64_t ctc_work_floats_per_clip(int T, int V, int S_max) { return 2 * ((int64_t)T * V + (int64_t)T * (2 * S_max + 1)); }
 
 paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
                float grad_scale, float* nll, float* dlogits, float* work, hipStream_t st) {
     if (S_max < 1 || S_max > 4000) PAA_FAIL(PAA_ERR_SIZE, "ctc: S_max=%d out of range", S_max);
     if (V > 256) PAA_FAIL(PAA_ERR_SIZE, "ctc: vocab %d > 256", V);
+    if ((uintptr_t)work & 7) PAA_FAIL(PAA_ERR_ARG, "ctc: work buffer must be 8-byte aligned");
     const int SPmax = 2 * S_max + 1;
-    const size_t lds = sizeof(float) * (3 * (size_t)SPmax + V);
+    const size_t lds = sizeof(double) * 2 * (size_t)SPmax + sizeof(int) * ((size_t)SPmax + V);
     hipLaunchKernelGGL(k_ctc, dim3(B), dim3(256), lds, st, logits, labels, T, Tpad, V, S_max, blank, grad_scale, nll,
-                       dlogits, work, ctc_work_floats_per_clip(T, V, S_max));
+                       dlogits, work, ctc_work_floats_per_clip(T, V, S_max) / 2);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }

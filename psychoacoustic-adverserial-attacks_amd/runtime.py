@@ -42,7 +42,8 @@ class Proj:
         """spl_thresh: the (1, F, 1) tensor of build.init_phon_threshold_tensor (uploaded when it changes)."""
         if spl_thresh is None:
             return
-        key = (spl_thresh.data_ptr(), spl_thresh._version)
+        # identity + version; the tensor is kept alive so its id / storage cannot be recycled by another contour
+        key = (id(spl_thresh), spl_thresh._version)
         if key == self._thr_key:
             return
         host = np.ascontiguousarray(spl_thresh.detach().reshape(-1).to("cpu", torch.float32).numpy())
@@ -51,6 +52,7 @@ class Proj:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().paa_proj_set_spl_thresh(self.h, host.ctypes.data_as(C.c_void_p)))
         self._thr_key = key
+        self._thr_ref = spl_thresh
 
     def __del__(self):
         try:

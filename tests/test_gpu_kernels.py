@@ -156,7 +156,10 @@ def test_ctc(T, S_max, lens):
         labels[b, :n] = torch.randint(1, V, (n,))
         if n > 3:
             labels[b, 2] = labels[b, 1]            # a repeated label forces the blank transition rule
-    lr = logits.clone().requires_grad_(True)
+    # float64 torch reference: torch's float32 CPU kernel itself carries ~1e-3 relative noise in the gradient at
+    # T=499 (alpha + beta + nll cancels numbers of magnitude 1e3), so the check is against the exact value and the
+    # float32 result is only required to be as close to it as torch-float32 is.
+    lr = logits.double().clone().requires_grad_(True)
     lp = F.log_softmax(lr, -1).transpose(0, 1)
     mask = labels >= 0
     nll = F.ctc_loss(lp, labels.masked_select(mask), torch.full((B,), T), mask.sum(-1), blank=0, reduction="none",
@@ -174,4 +177,4 @@ def test_ctc(T, S_max, lens):
     e1 = rel_err(out_nll.cpu()[fin], nll.detach()[fin])
     e2 = rel_err(dl.cpu()[fin], lr.grad[fin])
     print(f"ctc T={T}: nll {e1:.2e} grad {e2:.2e}")
-    assert e1 < 2e-6 and e2 < 5e-5
+    assert e1 < 2e-6 and e2 < 2e-6
