@@ -140,11 +140,11 @@ int paa_model_layout(const paa_model* m, int i);  /* padded rows of conv layer i
 struct paa_gemm_desc;
 paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
 /* Measurement aid (bench.py roofline leg): HIP-event timing of every GEMM launch on its own stream.
- * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[16][3] =
+ * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[32][3] =
  * {launches, total ms, total algorithmic FLOP (2*M*N*K*batch)} per kernel variant
- * (narrow*8 + split*4 + a_kcontig*2 + b_kcontig) and resets the counters. */
+ * (bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig) and resets the counters. */
 paa_status paa_prof_enable(int max_launches);
-paa_status paa_prof_read(double* out48);
+paa_status paa_prof_read(double* out96);
 paa_status paa_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats,
                              int rows, int cols, float eps, void* stream);
 paa_status paa_layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, float* dx,

@@ -45,7 +45,9 @@ class PaaGemmDesc(C.Structure):
                 ("C_pre", C.c_void_p), ("aux", C.c_void_p), ("ld_aux", C.c_int64), ("aux_s1", C.c_int64),
                 ("aux_s2", C.c_int64), ("residual", C.c_void_p), ("ld_res", C.c_int64), ("res_s1", C.c_int64),
                 ("res_s2", C.c_int64), ("row_period", C.c_int32), ("row_valid", C.c_int32),
-                ("accumulate", C.c_int32), ("precision", C.c_int32)]
+                ("accumulate", C.c_int32), ("precision", C.c_int32),
+                ("operand_bf16", C.c_int32), ("A_lo", C.c_void_p), ("B_lo", C.c_void_p), ("Cb", C.c_void_p),
+                ("Cb_lo", C.c_void_p)]
 
 
 _SIGS = {

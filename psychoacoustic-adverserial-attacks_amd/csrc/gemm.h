@@ -1,8 +1,11 @@
 // Descriptor of the one MFMA GEMM every conv / linear / attention product of the PGD step uses.
 //   C[z][m][n] = epilogue( sum_k A[z][m][k] * B[z][k][n] )        m < M, n < N, k < K, z < batch
-// Operands and result are f32 in HBM; operands are converted to bf16 (precision 0) or split into
-// bf16 hi + lo (precision 1, three MFMA passes: hi*hi + hi*lo + lo*hi) on their way into LDS, and
-// accumulated in f32 by v_mfma_f32_32x32x16_bf16.
+// MFMA operands are bf16 (precision 0) or split bf16 hi + lo (precision 1, three MFMA passes:
+// hi*hi + hi*lo + lo*hi, fp32-parity), accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Two operand
+// formats: operand_bf16 = 1 — A and B are bf16 planes in HBM (hi, plus lo planes in split mode), both
+// K-contiguous: the fast path every conv / linear product takes (its producers write the bf16 planes
+// in their epilogues); operand_bf16 = 0 — f32 operands converted on their way into LDS, with the
+// transposed layouts the materialised-attention products need.
 #pragma once
 #include <stdint.h>
 
@@ -48,6 +51,15 @@ typedef struct paa_gemm_desc {
     int32_t row_period, row_valid;
     int32_t accumulate;
     int32_t precision;   // 0 = bf16, 1 = split bf16 (fp32-parity)
+    // bf16 operand / result planes (uint16 bit patterns).  operand_bf16: A, B (and A_lo, B_lo when precision = 1)
+    // point to bf16; strides stay in elements; lda, ldb, a_kseg, batch strides must be multiples of 8, K of 8.
+    int32_t operand_bf16;
+    const void* A_lo;
+    const void* B_lo;
+    // optional bf16 copies of the result (same ldc / batch strides as C): Cb = bf16(v), Cb_lo = bf16(v - Cb).
+    // C itself may be null when only the bf16 result is wanted.
+    void* Cb;
+    void* Cb_lo;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

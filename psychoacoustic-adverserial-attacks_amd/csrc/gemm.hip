@@ -23,13 +23,62 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int G_BM = 128, G_BK = 32, G_LD = 40 /* bf16 per LDS row */, G_NT = 256;
 
-__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
-__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
 struct GemmArgs {
     paa_gemm_desc d;
     int tiles_m, tiles_n;
 };
+
+// ---- epilogue shared by both main loops ---------------------------------------------------------
+template <int BN>
+__device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[2][BN / 64], int m0, int n0, int z1, int z2,
+                                         int wm, int wn, int lr, int lh) {
+    constexpr int NJ = BN / 64;
+    const int64_t coff = z1 * d.c_s1 + z2 * d.c_s2;
+    float* C = d.C ? d.C + coff : nullptr;
+    float* Cp = d.C_pre ? d.C_pre + coff : nullptr;
+    unsigned short* Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + coff : nullptr;
+    unsigned short* Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + coff : nullptr;
+    const float* aux = d.aux ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2 : nullptr;
+    const float* res = d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr;
+    const float* bias = d.bias ? d.bias + z2 * d.bias_s2 : nullptr;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + lr;
+        if (n >= d.N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= d.M) continue;
+                float v = acc[i][j][e] * d.alpha + bv;
+                const int64_t ci = (int64_t)m * d.ldc + n;
+                if (d.act == PAA_ACT_GELU) {
+                    if (Cp) Cp[ci] = v;
+                    v = gelu_f(v);
+                } else if (d.act == PAA_ACT_GELU_GRAD) {
+                    v *= gelu_grad_f(aux[(int64_t)m * d.ld_aux + n]);
+                }
+                if (res) v += res[(int64_t)m * d.ld_res + n];
+                if (d.row_period > 0 && (m % d.row_period) >= d.row_valid) {
+                    v = 0.f;
+                    if (Cp) Cp[ci] = 0.f;
+                }
+                if (C) {
+                    if (d.accumulate) v += C[ci];
+                    C[ci] = v;
+                }
+                if (Cb) {
+                    const unsigned short h = bf16_bits(v);
+                    Cb[ci] = h;
+                    if (Cbl) Cbl[ci] = bf16_bits(v - bf16_to_f32(h));
+                }
+            }
+        }
+    }
+}
 
 // ---- global -> register tile loads --------------------------------------------------------------
 // K-contiguous operand: ROWS x 32 tile, thread (r = tid>>3 [+32 i], kv = tid&7) loads float4 at k0 + 4 kv.
@@ -212,40 +261,141 @@ __global__ __launch_bounds__(G_NT) void k_gemm(GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------
-    float* C = d.C + z1 * d.c_s1 + z2 * d.c_s2;
-    float* Cp = d.C_pre ? d.C_pre + z1 * d.c_s1 + z2 * d.c_s2 : nullptr;
-    const float* aux = d.aux ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2 : nullptr;
-    const float* res = d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr;
-    const float* bias = d.bias ? d.bias + z2 * d.bias_s2 : nullptr;
+    epilogue<BN>(d, acc, m0, n0, z1, z2, wm, wn, lr, lh);
+}
+
+// ---- bf16-operand main loop ------------------------------------------------------------------------
+// Both operands K-contiguous bf16 planes.  Tile 128 x BN x 64; a thread moves 16-byte chunks (8 bf16) global ->
+// registers -> LDS (ds_write_b128) with no conversion work, rows padded to 72 bf16 (144 B: the four
+// ds_read_b128 lane groups hit 16 distinct 16-byte slots).  16 (BN=128) MFMAs per wave per K tile.
+constexpr int H_BK = 64, H_LD = 72;
+
+template <int ROWS, bool IS_A>
+__device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned short* __restrict__ base, int64_t ld,
+                                        int r0, int k0, int rlim, uint4 (&v)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+    const int k = k0 + ((tid & 7) << 3);
+    int64_t koff = k;
+    int js = 0, kc = k;
+    if (IS_A && d.a_kseg > 0) {
+        js = k / d.a_kseg;
+        kc = k - js * d.a_kseg;
+        koff = (int64_t)js * d.a_kseg_stride + kc;
+    }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + lr;
-        if (n >= d.N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int r = r0 + (tid >> 3) + 32 * i;
+        uint4 x = make_uint4(0u, 0u, 0u, 0u);
+        bool ok = (r < rlim) && (k < d.K);
+        const unsigned short* p;
+        if (IS_A && d.a_window) {
+            const int tr = r + js - d.a_pad;
+            ok = ok && (tr >= 0) && (tr < d.a_rows_valid);
+            p = base + (int64_t)tr * ld + kc;
+        } else {
+            p = base + (int64_t)r * ld + koff;
+        }
+        if (ok) x = *reinterpret_cast<const uint4*>(p);
+        v[i] = x;
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void store_bf(unsigned short* lds, const uint4 (&v)[ROWS / 32]) {
+    const int tid = threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i)
+        *reinterpret_cast<uint4*>(lds + ((tid >> 3) + 32 * i) * H_LD + ((tid & 7) << 3)) = v[i];
+}
+
+template <int BN, int PREC>
+__global__ __launch_bounds__(G_NT) void k_gemm_bf(GemmArgs g) {
+    constexpr int NPL = PREC ? 2 : 1;
+    constexpr int NJ = BN / 64;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[NPL * (G_BM + BN) * H_LD];
+    unsigned short* sAh = smem;
+    unsigned short* sAl = smem + (PREC ? G_BM * H_LD : 0);
+    unsigned short* sBh = smem + NPL * G_BM * H_LD;
+    unsigned short* sBl = sBh + (PREC ? BN * H_LD : 0);
+
+    const paa_gemm_desc& d = g.d;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int orig = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+    const int m0 = tm * G_BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int z1 = z / d.batch2, z2 = z - z1 * d.batch2;
+    const int64_t aoff = z1 * d.a_s1 + z2 * d.a_s2, boff = z1 * d.b_s1 + z2 * d.b_s2;
+    const unsigned short* Ah = reinterpret_cast<const unsigned short*>(d.A) + aoff;
+    const unsigned short* Bh = reinterpret_cast<const unsigned short*>(d.B) + boff;
+    const unsigned short* Al = PREC ? reinterpret_cast<const unsigned short*>(d.A_lo) + aoff : nullptr;
+    const unsigned short* Bl = PREC ? reinterpret_cast<const unsigned short*>(d.B_lo) + boff : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[2][NJ];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m >= d.M) continue;
-                float v = acc[i][j][e] * d.alpha + bv;
-                if (d.act == PAA_ACT_GELU) {
-                    if (Cp) Cp[(int64_t)m * d.ldc + n] = v;
-                    v = gelu_f(v);
-                } else if (d.act == PAA_ACT_GELU_GRAD) {
-                    v *= gelu_grad_f(aux[(int64_t)m * d.ld_aux + n]);
-                }
-                if (res) v += res[(int64_t)m * d.ld_res + n];
-                if (d.row_period > 0 && (m % d.row_period) >= d.row_valid) {
-                    v = 0.f;
-                    if (Cp) Cp[(int64_t)m * d.ldc + n] = 0.f;
-                }
-                float* c = C + (int64_t)m * d.ldc + n;
-                *c = d.accumulate ? (*c + v) : v;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 rah[G_BM / 32], rbh[BN / 32], ral[PREC ? G_BM / 32 : 1], rbl[PREC ? BN / 32 : 1];
+    const int nk = (d.K + H_BK - 1) / H_BK;
+    load_bf<G_BM, true>(d, Ah, d.lda, m0, 0, d.M, rah);
+    load_bf<BN, false>(d, Bh, d.ldb, n0, 0, d.N, rbh);
+    if constexpr (PREC) {
+        load_bf<G_BM, true>(d, Al, d.lda, m0, 0, d.M, ral);
+        load_bf<BN, false>(d, Bl, d.ldb, n0, 0, d.N, rbl);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        store_bf<G_BM>(sAh, rah);
+        store_bf<BN>(sBh, rbh);
+        if constexpr (PREC) { store_bf<G_BM>(sAl, ral); store_bf<BN>(sBl, rbl); }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int k0 = (kt + 1) * H_BK;
+            load_bf<G_BM, true>(d, Ah, d.lda, m0, k0, d.M, rah);
+            load_bf<BN, false>(d, Bh, d.ldb, n0, k0, d.N, rbh);
+            if constexpr (PREC) {
+                load_bf<G_BM, true>(d, Al, d.lda, m0, k0, d.M, ral);
+                load_bf<BN, false>(d, Bl, d.ldb, n0, k0, d.N, rbl);
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < H_BK / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + lr) * H_LD + ks * 16 + lh * 8;
+                ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
+                if (PREC) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int off = (wn * (BN / 2) + j * 32 + lr) * H_LD + ks * 16 + lh * 8;
+                bh[j] = *reinterpret_cast<const bf16x8*>(sBh + off);
+                if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sBl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (PREC) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
     }
+    epilogue<BN>(d, acc, m0, n0, z1, z2, wm, wn, lr, lh);
 }
 
 template <int BN, int PREC>
@@ -268,12 +418,20 @@ struct GemmProf {
 static GemmProf g_prof;
 
 paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
-    if (!d.A || !d.B || !d.C) PAA_FAIL(PAA_ERR_ARG, "gemm: null operand");
+    if (!d.A || !d.B || (!d.C && !d.Cb)) PAA_FAIL(PAA_ERR_ARG, "gemm: null operand");
+    if (d.accumulate && !d.C) PAA_FAIL(PAA_ERR_ARG, "gemm: accumulate needs the f32 result");
+    if (d.Cb_lo && !d.Cb) PAA_FAIL(PAA_ERR_ARG, "gemm: Cb_lo without Cb");
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0 || d.batch2 <= 0) PAA_FAIL(PAA_ERR_SIZE, "gemm: bad dims %d %d %d", d.M, d.N, d.K);
-    if ((d.lda & 3) || (d.ldb & 3) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15))
-        PAA_FAIL(PAA_ERR_ARG, "gemm: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
-    if ((d.a_s1 & 3) || (d.a_s2 & 3) || (d.b_s1 & 3) || (d.b_s2 & 3)) PAA_FAIL(PAA_ERR_ARG, "gemm: batch strides must be multiples of 4");
-    if (d.a_kseg > 0 && ((d.a_kseg & 3) || (d.a_kseg_stride & 3) || !d.a_kcontig)) PAA_FAIL(PAA_ERR_ARG, "gemm: bad K segmentation");
+    const int al = d.operand_bf16 ? 7 : 3;     // elements per 16-byte vector - 1
+    if ((d.lda & al) || (d.ldb & al) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15))
+        PAA_FAIL(PAA_ERR_ARG, "gemm: operands must be 16-byte aligned with leading dimensions that are multiples of %d", al + 1);
+    if ((d.a_s1 & al) || (d.a_s2 & al) || (d.b_s1 & al) || (d.b_s2 & al)) PAA_FAIL(PAA_ERR_ARG, "gemm: batch strides must be multiples of %d", al + 1);
+    if (d.a_kseg > 0 && ((d.a_kseg & al) || (d.a_kseg_stride & al) || !d.a_kcontig)) PAA_FAIL(PAA_ERR_ARG, "gemm: bad K segmentation");
+    if (d.operand_bf16) {
+        if (!d.a_kcontig || !d.b_kcontig || (d.K & 7)) PAA_FAIL(PAA_ERR_ARG, "gemm: bf16 operands must be K-contiguous with K %% 8 == 0 (K=%d)", d.K);
+        if (d.precision && (!d.A_lo || !d.B_lo || ((uintptr_t)d.A_lo & 15) || ((uintptr_t)d.B_lo & 15)))
+            PAA_FAIL(PAA_ERR_ARG, "gemm: split precision needs aligned lo planes");
+    }
     if (d.a_window && d.a_kseg <= 0) PAA_FAIL(PAA_ERR_ARG, "gemm: a_window needs a_kseg");
     if (d.act == PAA_ACT_GELU_GRAD && !d.aux) PAA_FAIL(PAA_ERR_ARG, "gemm: GELU_GRAD needs aux");
     GemmArgs g;
@@ -287,9 +445,12 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
         g_prof.flops[g_prof.n] = 2.0 * d.M * d.N * (double)d.K * d.batch;
-        g_prof.variant[g_prof.n] = (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
+        g_prof.variant[g_prof.n] = (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     }
-    if (narrow) { if (d.precision) launch_gemm<64, 1>(g, grid, st); else launch_gemm<64, 0>(g, grid, st); }
+    if (d.operand_bf16) {
+        if (narrow) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<64, 1>), grid, dim3(G_NT), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<64, 0>), grid, dim3(G_NT), 0, st, g); }
+        else { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 1>), grid, dim3(G_NT), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 0>), grid, dim3(G_NT), 0, st, g); }
+    } else if (narrow) { if (d.precision) launch_gemm<64, 1>(g, grid, st); else launch_gemm<64, 0>(g, grid, st); }
     else { if (d.precision) launch_gemm<128, 1>(g, grid, st); else launch_gemm<128, 0>(g, grid, st); }
     if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }
     PAA_LAUNCH_CHECK();
@@ -312,19 +473,19 @@ extern "C" paa_status paa_prof_enable(int max_launches) {
     return PAA_OK;
 }
 
-// out[16][3] = per kernel variant (narrow*8 + split*4 + a_kcontig*2 + b_kcontig): launches, total ms, total FLOP.
+// out[32][3] = per kernel variant (bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig): launches, total ms, total FLOP.
 // Synchronises on the last recorded event.  Resets the counters.
-extern "C" paa_status paa_prof_read(double* out48) {
+extern "C" paa_status paa_prof_read(double* out96) {
     using namespace paa;
-    if (!out48) PAA_FAIL(PAA_ERR_ARG, "paa_prof_read: null");
-    for (int i = 0; i < 48; ++i) out48[i] = 0.0;
+    if (!out96) PAA_FAIL(PAA_ERR_ARG, "paa_prof_read: null");
+    for (int i = 0; i < 96; ++i) out96[i] = 0.0;
     if (g_prof.n == 0) return PAA_OK;
     PAA_HIP(hipEventSynchronize(g_prof.ev[2 * g_prof.n - 1]));
     for (size_t i = 0; i < g_prof.n; ++i) {
         float ms = 0.f;
         PAA_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
         const int v = g_prof.variant[i];
-        out48[3 * v] += 1.0; out48[3 * v + 1] += ms; out48[3 * v + 2] += g_prof.flops[i];
+        out96[3 * v] += 1.0; out96[3 * v + 1] += ms; out96[3 * v + 2] += g_prof.flops[i];
     }
     g_prof.n = 0;
     return PAA_OK;

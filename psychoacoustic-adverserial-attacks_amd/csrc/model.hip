@@ -4,14 +4,21 @@
 //   core/loss_helpers.py:21  model(input_values=perturbed, labels=labels)   [HF modeling_wav2vec2.py:1667-1736]
 //   train.py:158             (direction * loss).backward()                   [input gradient only]
 //
-// Layout.  Every activation is channel-last f32.  The feature encoder keeps P_i >= T_i rows per clip
-// with P_{i-1} = stride_i * P_i, so layer i's im2col matrix over the WHOLE batch is a plain strided view
-// of layer i-1's output (row m starts at row stride_i*m, K = k_i*C contiguous floats, lda = stride_i*C):
+// Layout.  Every activation is channel-last.  The feature encoder keeps P_i >= T_i rows per clip with
+// P_{i-1} = stride_i * P_i, so layer i's im2col matrix over the WHOLE batch is a plain strided view of
+// layer i-1's output (row m starts at row stride_i*m, K = k_i*C contiguous elements, lda = stride_i*C):
 // each strided 1-D convolution is ONE GEMM with overlapping A rows, and its input gradient is one GEMM
 // per residue class of the stride.  Pad rows are kept at zero.  The transformer runs on the same padded
 // row space (M = B * P_last); attention and the grouped positional convolution address clips
 // individually through the GEMM's batch strides / time window.
-// No weight gradients are computed (the reference computes and discards them).
+//
+// Precision.  Every tensor that is a conv / linear GEMM operand exists in HBM as bf16 planes written by
+// its producer's epilogue ("H" buffers: hi, plus lo = bf16(v - hi) in fp32-parity mode); tensors read by
+// element-wise kernels (norm inputs, residual streams, pre-activations) stay f32 ("F" buffers).  Weights
+// are packed to bf16 planes once on the host.  No weight gradients are computed (the reference computes
+// and discards them).
+#include <string.h>
+
 #include <map>
 #include <string>
 #include <vector>
@@ -22,16 +29,28 @@ using namespace paa;
 
 namespace {
 
+struct CBf {                       // read-only bf16 planes
+    const unsigned short* hi = nullptr;
+    const unsigned short* lo = nullptr;
+    CBf off(int64_t e) const { return CBf{hi + e, lo ? lo + e : nullptr}; }
+};
+static inline CBf ro(const Bf& b) { return CBf{b.hi, b.lo}; }
+static inline Bf boff(const Bf& b, int64_t e) { return Bf{b.hi + e, b.lo ? b.lo + e : nullptr}; }
+static const Bf NOBF{nullptr, nullptr};
+
 struct ConvL {
     int cin, cout, k, s, T, P;
-    const float *w = nullptr, *b = nullptr, *g = nullptr, *beta = nullptr;
-    std::vector<const float*> wd;      // per residue class of the stride: [cin][(Q+1)*cout]
+    const float *w0 = nullptr, *b = nullptr, *g = nullptr, *beta = nullptr;   // w0: conv0 weights (f32)
+    CBf w;                             // [cout][k*cin]
+    std::vector<CBf> wd;               // per residue class of the stride: [cin][(Q+1)*cout]
     std::vector<int> wdQ;
-    float *pre = nullptr, *act = nullptr, *cv = nullptr, *row_stats = nullptr;
+    float *pre = nullptr, *act_f = nullptr, *cv = nullptr, *row_stats = nullptr;
+    Bf actb{nullptr, nullptr};
 };
 
 struct EncL {
-    const float *wqkv, *bqkv, *wqkv_t, *wo, *bo, *wo_t, *ln1_g, *ln1_b, *w1, *b1, *w1_t, *w2, *b2, *w2_t, *ln2_g, *ln2_b;
+    CBf wqkv, wqkv_t, wo, wo_t, w1, w1_t, w2, w2_t;
+    const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b;
     float *qkv, *P, *ln1_in, *st1, *fpre, *ln2_in, *st2;
 };
 
@@ -45,11 +64,14 @@ __global__ void k_copy_logits(const float* __restrict__ src, float* __restrict__
     }
 }
 
-// out[b][t][c] = dy[b][t][c] * gelu'(pre[b][t][c]) for valid rows
+// out = dy * gelu'(pre)   (f32 and / or bf16 planes)
 __global__ void k_mul_gelu_grad(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ out,
-                                int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = dy[i] * gelu_grad_f(pre[i]);
+                                Bf outb, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = dy[i] * gelu_grad_f(pre[i]);
+        if (out) out[i] = v;
+        store_bf16(outb, i, v);
+    }
 }
 
 }  // namespace
@@ -62,15 +84,20 @@ struct paa_model {
     std::vector<EncL> enc;
     std::map<std::string, std::pair<const float*, int64_t>> tensors;
     // weights
-    const float *fp_ln_g, *fp_ln_b, *fp_w, *fp_b, *fp_wt, *pc_w, *pc_b, *pc_wd, *enc_ln_g, *enc_ln_b, *lm_w, *lm_b, *lm_wt;
+    const float *fp_ln_g, *fp_ln_b, *fp_b, *pc_b, *enc_ln_g, *enc_ln_b, *lm_b;
+    CBf fp_w, fp_wt, pc_w, pc_wd, lm_w, lm_wt;
     // workspace
     float* arena = nullptr;
     int64_t arena_floats = 0;
     float *gn_stats, *gn_bsums, *c0_part, *G;
-    float *gbuf[2];
-    float *fn, *fp_stats, *h0, *pos_pre, *hsum, *enc_stats, *xa, *xb, *ctx, *fact, *xfinal, *final_in;
+    float* gF[2];                    // f32 conv-stack gradients (conv0's input; every layer under the layer-norm variant)
+    Bf gH[2];                        // bf16 conv-stack gradients (dgrad GEMM operands), with zero guard rows in front
+    float* gz;
+    Bf fnH, h0H, xaH, xbH, ctxH, factH, xfinalH;
+    float *fp_stats, *h0, *pos_pre, *hsum, *enc_stats, *xa, *xb, *final_in;
     float *logits, *dlogits, *nll, *ctc_work;
-    float *dxa, *dxb, *dqkv, *dctx, *dP, *dfpre, *dpos, *dh0, *dfn;
+    Bf dlogitsH, dxaH, dxbH, dqkvH, dfpreH, dposH, dh0H;
+    float *dxa, *dxb, *dctx, *dP, *dh0, *dfn;
     int S_cap;
 };
 
@@ -85,6 +112,10 @@ static const float* find(paa_model* m, const std::string& n, int64_t numel, paa_
     return it->second.first;
 }
 #define NEED(dst, name, numel) do { paa_status _st = PAA_OK; dst = find(m, name, numel, &_st); if (_st != PAA_OK) { paa_model_destroy(m); return _st; } } while (0)
+// bf16 weight planes: "<name>" (hi) and, in fp32-parity mode, "<name>.lo"
+#define NEEDB(dst, name, numel) do { const float* _h; const float* _l = nullptr; NEED(_h, name, numel); \
+    if (m->prec) NEED(_l, std::string(name) + ".lo", numel); \
+    dst = CBf{reinterpret_cast<const unsigned short*>(_h), reinterpret_cast<const unsigned short*>(_l)}; } while (0)
 
 extern "C" void paa_model_destroy(paa_model* m) {
     if (!m) return;
@@ -99,10 +130,10 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     if (!out || !arch || !tensors) PAA_FAIL(PAA_ERR_ARG, "paa_model_create: null argument");
     const paa_arch& a = *arch;
     if (a.n_conv < 2 || a.n_conv > 8) PAA_FAIL(PAA_ERR_ARG, "n_conv=%d unsupported", a.n_conv);
-    if (a.hidden % a.heads || (a.hidden / a.heads) % 4 || a.hidden % 4 || a.ffn % 4 || a.vocab % 4)
-        PAA_FAIL(PAA_ERR_ARG, "hidden/heads/ffn/vocab must give 16-byte aligned rows");
-    if (a.hidden % a.pos_groups || (a.hidden / a.pos_groups) % 4) PAA_FAIL(PAA_ERR_ARG, "pos-conv group width must be a multiple of 4");
-    for (int i = 0; i < a.n_conv; ++i) if (a.conv_dim[i] % 4) PAA_FAIL(PAA_ERR_ARG, "conv_dim must be multiples of 4");
+    if (a.hidden % a.heads || (a.hidden / a.heads) % 8 || a.hidden % 8 || a.ffn % 8 || a.vocab % 8)
+        PAA_FAIL(PAA_ERR_ARG, "hidden/heads/ffn/vocab must give 16-byte aligned bf16 rows");
+    if (a.hidden % a.pos_groups || (a.hidden / a.pos_groups) % 8) PAA_FAIL(PAA_ERR_ARG, "pos-conv group width must be a multiple of 8");
+    for (int i = 0; i < a.n_conv; ++i) if (a.conv_dim[i] % 8) PAA_FAIL(PAA_ERR_ARG, "conv_dim must be multiples of 8");
     if (max_batch < 1 || length < 1) PAA_FAIL(PAA_ERR_SIZE, "max_batch/length");
     paa_model* m = new paa_model();
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
@@ -141,33 +172,34 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     for (int i = 0; i < nc; ++i) {
         ConvL& c = m->conv[i];
         const std::string p = "c" + std::to_string(i);
-        NEED(c.w, p + ".w", (int64_t)c.cout * c.k * c.cin);
+        if (i == 0) NEED(c.w0, p + ".w", (int64_t)c.cout * c.k);
+        else NEEDB(c.w, p + ".w", (int64_t)c.cout * c.k * c.cin);
         if (a.conv_bias) NEED(c.b, p + ".b", c.cout);
         if ((a.feat_norm_layer == 0 && i == 0) || a.feat_norm_layer == 1) { NEED(c.g, p + ".g", c.cout); NEED(c.beta, p + ".beta", c.cout); }
         if (i > 0) {
             for (int rho = 0; rho < c.s; ++rho) {
-                if (rho > c.k - 1) { c.wd.push_back(nullptr); c.wdQ.push_back(-1); continue; }
+                if (rho > c.k - 1) { c.wd.push_back(CBf{}); c.wdQ.push_back(-1); continue; }
                 const int Q = (c.k - 1 - rho) / c.s;
-                const float* w;
-                NEED(w, p + ".wd" + std::to_string(rho), (int64_t)c.cin * (Q + 1) * c.cout);
+                CBf w;
+                NEEDB(w, p + ".wd" + std::to_string(rho), (int64_t)c.cin * (Q + 1) * c.cout);
                 c.wd.push_back(w); c.wdQ.push_back(Q);
             }
         }
     }
-    NEED(m->fp_ln_g, "fp.ln_g", C6); NEED(m->fp_ln_b, "fp.ln_b", C6);
-    NEED(m->fp_w, "fp.w", (int64_t)H * C6); NEED(m->fp_b, "fp.b", H); NEED(m->fp_wt, "fp.wt", (int64_t)H * C6);
-    NEED(m->pc_w, "pc.w", (int64_t)H * Hg * a.pos_k); NEED(m->pc_b, "pc.b", H); NEED(m->pc_wd, "pc.wd", (int64_t)H * Hg * a.pos_k);
+    NEED(m->fp_ln_g, "fp.ln_g", C6); NEED(m->fp_ln_b, "fp.ln_b", C6); NEED(m->fp_b, "fp.b", H);
+    NEEDB(m->fp_w, "fp.w", (int64_t)H * C6); NEEDB(m->fp_wt, "fp.wt", (int64_t)H * C6);
+    NEEDB(m->pc_w, "pc.w", (int64_t)H * Hg * a.pos_k); NEEDB(m->pc_wd, "pc.wd", (int64_t)H * Hg * a.pos_k); NEED(m->pc_b, "pc.b", H);
     NEED(m->enc_ln_g, "enc.ln_g", H); NEED(m->enc_ln_b, "enc.ln_b", H);
-    NEED(m->lm_w, "lm.w", (int64_t)V * H); NEED(m->lm_b, "lm.b", V); NEED(m->lm_wt, "lm.wt", (int64_t)V * H);
+    NEEDB(m->lm_w, "lm.w", (int64_t)V * H); NEEDB(m->lm_wt, "lm.wt", (int64_t)V * H); NEED(m->lm_b, "lm.b", V);
     m->enc.resize(a.layers);
     for (int l = 0; l < a.layers; ++l) {
         EncL& e = m->enc[l];
         const std::string p = "L" + std::to_string(l);
-        NEED(e.wqkv, p + ".wqkv", (int64_t)3 * H * H); NEED(e.bqkv, p + ".bqkv", 3 * H); NEED(e.wqkv_t, p + ".wqkv_t", (int64_t)3 * H * H);
-        NEED(e.wo, p + ".wo", (int64_t)H * H); NEED(e.bo, p + ".bo", H); NEED(e.wo_t, p + ".wo_t", (int64_t)H * H);
+        NEEDB(e.wqkv, p + ".wqkv", (int64_t)3 * H * H); NEEDB(e.wqkv_t, p + ".wqkv_t", (int64_t)3 * H * H); NEED(e.bqkv, p + ".bqkv", 3 * H);
+        NEEDB(e.wo, p + ".wo", (int64_t)H * H); NEEDB(e.wo_t, p + ".wo_t", (int64_t)H * H); NEED(e.bo, p + ".bo", H);
         NEED(e.ln1_g, p + ".ln1_g", H); NEED(e.ln1_b, p + ".ln1_b", H);
-        NEED(e.w1, p + ".w1", (int64_t)F * H); NEED(e.b1, p + ".b1", F); NEED(e.w1_t, p + ".w1_t", (int64_t)F * H);
-        NEED(e.w2, p + ".w2", (int64_t)F * H); NEED(e.b2, p + ".b2", H); NEED(e.w2_t, p + ".w2_t", (int64_t)F * H);
+        NEEDB(e.w1, p + ".w1", (int64_t)F * H); NEEDB(e.w1_t, p + ".w1_t", (int64_t)F * H); NEED(e.b1, p + ".b1", F);
+        NEEDB(e.w2, p + ".w2", (int64_t)F * H); NEEDB(e.w2_t, p + ".w2_t", (int64_t)F * H); NEED(e.b2, p + ".b2", H);
         NEED(e.ln2_g, p + ".ln2_g", H); NEED(e.ln2_b, p + ".ln2_b", H);
     }
 
@@ -181,38 +213,52 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
             off += n;
             return p;
         };
+        auto take_bf = [&](int64_t n) -> Bf {     // n bf16 elements per plane
+            Bf b;
+            b.hi = reinterpret_cast<unsigned short*>(take((n + 1) / 2));
+            b.lo = m->prec ? reinterpret_cast<unsigned short*>(take((n + 1) / 2)) : nullptr;
+            return b;
+        };
         const int64_t GUARD = 8;             // zero rows before / after a row-matrix (dgrad look-back, im2col look-ahead)
         int maxC = 0;
         for (int i = 0; i < nc; ++i) maxC = std::max(maxC, a.conv_dim[i]);
         for (int i = 0; i < nc; ++i) {
             ConvL& c = m->conv[i];
             const int64_t n = ((int64_t)B * c.P + GUARD) * c.cout;
-            c.pre = take(n); c.act = take(n);
+            c.pre = take(n);
+            if (i < nc - 1) c.actb = take_bf(n); else c.act_f = take(n);
             if (a.feat_norm_layer) { if (i) c.cv = take(n); c.row_stats = take((int64_t)B * c.P * 2); }
         }
         const ConvL& c0 = m->conv[0];
         m->gn_stats = take((int64_t)B * c0.cout * 2); m->gn_bsums = take((int64_t)B * c0.cout * 2);
         m->c0_part = take((int64_t)B * conv0_chunks(c0.T) * c0.cout * 2);
         m->G = take((int64_t)B * c0.P * c0.k);
+        const int64_t gsz = ((int64_t)B * c0.P + 2 * GUARD) * maxC;
         for (int j = 0; j < 2; ++j) {
-            float* p = take(((int64_t)B * c0.P + 2 * GUARD) * maxC);
-            m->gbuf[j] = pass ? p + GUARD * maxC : nullptr;
+            float* p = (a.feat_norm_layer || j == 0) ? take(gsz) : nullptr;
+            m->gF[j] = (pass && p) ? p + GUARD * maxC : nullptr;
+            Bf h = take_bf(gsz);
+            m->gH[j] = pass ? boff(h, GUARD * maxC) : NOBF;
         }
-        const int64_t MH = (int64_t)m->M * H, MF = (int64_t)m->M * F;
-        m->fn = take((int64_t)m->M * C6); m->fp_stats = take((int64_t)m->M * 2);
-        m->h0 = take(MH); m->pos_pre = take(MH); m->hsum = take(MH); m->enc_stats = take((int64_t)m->M * 2);
-        m->xa = take(MH); m->xb = take(MH); m->ctx = take(MH); m->fact = take(MF); m->xfinal = take(MH); m->final_in = take(MH);
+        const int64_t MH = (int64_t)m->M * H, MF = (int64_t)m->M * F, MC = (int64_t)m->M * C6;
+        m->gz = take(MC);
+        m->fnH = take_bf(MC); m->fp_stats = take((int64_t)m->M * 2);
+        m->h0 = take(MH); m->h0H = take_bf(MH); m->pos_pre = take(MH); m->hsum = take(MH); m->enc_stats = take((int64_t)m->M * 2);
+        m->xa = take(MH); m->xaH = take_bf(MH); m->xb = take(MH); m->xbH = take_bf(MH);
+        m->ctxH = take_bf(MH); m->factH = take_bf(MF); m->xfinalH = take_bf(MH); m->final_in = take(MH);
         const int64_t PM = (int64_t)B * nh * m->Tp * m->Tp;
         for (int l = 0; l < a.layers; ++l) {
             EncL& e = m->enc[l];
             e.qkv = take(3 * MH); e.P = take(PM); e.ln1_in = take(MH); e.st1 = take((int64_t)m->M * 2);
             e.fpre = take(MF); e.ln2_in = take(MH); e.st2 = take((int64_t)m->M * 2);
         }
-        m->logits = take((int64_t)m->M * V); m->dlogits = take((int64_t)m->M * V); m->nll = take(B);
+        m->logits = take((int64_t)m->M * V); m->dlogits = take((int64_t)m->M * V); m->dlogitsH = take_bf((int64_t)m->M * V);
+        m->nll = take(B);
         m->S_cap = std::max(1, std::min(4000, m->T));     // labels longer than T_e are infeasible anyway
         m->ctc_work = take((int64_t)B * ctc_work_floats_per_clip(m->T, V, m->S_cap));
-        m->dxa = take(MH); m->dxb = take(MH); m->dqkv = take(3 * MH); m->dctx = take(MH); m->dP = take(PM);
-        m->dfpre = take(MF); m->dpos = take(MH); m->dh0 = take(MH); m->dfn = take((int64_t)m->M * C6);
+        m->dxa = take(MH); m->dxaH = take_bf(MH); m->dxb = take(MH); m->dxbH = take_bf(MH);
+        m->dqkvH = take_bf(3 * MH); m->dctx = take(MH); m->dP = take(PM);
+        m->dfpreH = take_bf(MF); m->dposH = take_bf(MH); m->dh0 = take(MH); m->dh0H = take_bf(MH); m->dfn = take(MC);
         if (!pass) {
             m->arena_floats = off;
             hipError_t e = hipMalloc(&m->arena, sizeof(float) * off);
@@ -229,6 +275,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
 }
 
 // ---------------------------------------------------------------------------------------------------
+// f32-operand descriptor (materialised attention products)
 static paa_gemm_desc gd(const paa_model* m, const float* A, const float* Bm, float* C, int M, int N, int K, int64_t lda,
                         int64_t ldb, int64_t ldc) {
     paa_gemm_desc d{};
@@ -236,11 +283,23 @@ static paa_gemm_desc gd(const paa_model* m, const float* A, const float* Bm, flo
     d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;
     return d;
 }
+// bf16-operand descriptor (every conv / linear product)
+static paa_gemm_desc gdb(const paa_model* m, CBf A, CBf W, float* C, Bf Cb, int M, int N, int K, int64_t lda, int64_t ldb,
+                         int64_t ldc) {
+    paa_gemm_desc d{};
+    d.operand_bf16 = 1;
+    d.A = reinterpret_cast<const float*>(A.hi); d.A_lo = A.lo; d.B = reinterpret_cast<const float*>(W.hi); d.B_lo = W.lo;
+    d.C = C; d.Cb = Cb.hi; d.Cb_lo = Cb.lo;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
+    d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;
+    return d;
+}
 
-static paa_status linear(const paa_model* m, const float* x, const float* w, const float* bias, float* y, int M, int N,
-                         int K, hipStream_t st, const float* residual = nullptr, int act = 0, float* pre = nullptr,
+// y = x W^T (+bias) (+epilogue): x (M, K) bf16 planes, W [N][K] bf16 planes
+static paa_status linear(const paa_model* m, CBf x, CBf w, const float* bias, float* y, Bf yb, int M, int N, int K,
+                         hipStream_t st, const float* residual = nullptr, int act = 0, float* pre = nullptr,
                          const float* aux = nullptr) {
-    paa_gemm_desc d = gd(m, x, w, y, M, N, K, K, K, N);
+    paa_gemm_desc d = gdb(m, x, w, y, yb, M, N, K, K, K, N);
     d.bias = bias; d.residual = residual; d.ld_res = N; d.act = act; d.C_pre = pre; d.aux = aux; d.ld_aux = N;
     return gemm(d, st);
 }
@@ -254,30 +313,33 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         ConvL& c = m->conv[0];
         Conv0Args ca{};
         ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
-        ca.k = c.k; ca.stride = c.s; ca.w = c.w; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
-        ca.pre = c.pre; ca.act = c.act; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
+        ca.k = c.k; ca.stride = c.s; ca.w = c.w0; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
+        ca.pre = c.pre; ca.actb = c.actb; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
         if (a.feat_norm_layer) PAA_TRY(conv0_ln_forward(ca, st)); else PAA_TRY(conv0_gn_forward(ca, m->c0_part, st));
     }
     for (int i = 1; i < nc; ++i) {
         ConvL& c = m->conv[i];
         const ConvL& pr = m->conv[i - 1];
         const int K = c.k * c.cin;
-        paa_gemm_desc d = gd(m, pr.act, c.w, nullptr, B * c.P, c.cout, K, (int64_t)c.s * c.cin, K, c.cout);
+        const bool last = i == nc - 1;
+        paa_gemm_desc d = gdb(m, ro(pr.actb), c.w, nullptr, NOBF, B * c.P, c.cout, K, (int64_t)c.s * c.cin, K, c.cout);
         d.bias = c.b; d.row_period = c.P; d.row_valid = c.T;
         if (a.feat_norm_layer) {
             d.C = c.cv;
             PAA_TRY(gemm(d, st));
-            PAA_TRY(layernorm_fwd(c.cv, c.g, c.beta, c.pre, c.row_stats, B * c.P, c.cout, 1e-5f, c.act, st));
+            PAA_TRY(layernorm_fwd(c.cv, c.g, c.beta, c.pre, c.row_stats, B * c.P, c.cout, 1e-5f, NOBF, last ? NOBF : c.actb,
+                                  last ? c.act_f : nullptr, st));
         } else {
-            d.C = c.act; d.C_pre = c.pre; d.act = PAA_ACT_GELU;
+            d.C_pre = c.pre; d.act = PAA_ACT_GELU;
+            if (last) d.C = c.act_f; else { d.Cb = c.actb.hi; d.Cb_lo = c.actb.lo; }
             PAA_TRY(gemm(d, st));
         }
     }
     // ---- feature projection: LN + Linear (pad rows forced to zero) ----
     const ConvL& cl = m->conv[nc - 1];
-    PAA_TRY(layernorm_fwd(cl.act, m->fp_ln_g, m->fp_ln_b, m->fn, m->fp_stats, M, cl.cout, a.ln_eps, nullptr, st));
+    PAA_TRY(layernorm_fwd(cl.act_f, m->fp_ln_g, m->fp_ln_b, nullptr, m->fp_stats, M, cl.cout, a.ln_eps, m->fnH, NOBF, nullptr, st));
     {
-        paa_gemm_desc d = gd(m, m->fn, m->fp_w, m->h0, M, H, cl.cout, cl.cout, cl.cout, H);
+        paa_gemm_desc d = gdb(m, ro(m->fnH), m->fp_w, m->h0, m->h0H, M, H, cl.cout, cl.cout, cl.cout, H);
         d.bias = m->fp_b; d.row_period = P; d.row_valid = T;
         PAA_TRY(gemm(d, st));
     }
@@ -285,7 +347,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
     float* enc_in = a.stable_ln ? m->enc[0].ln1_in : m->hsum;
     {
         const int K = a.pos_k * Hg;
-        paa_gemm_desc d = gd(m, m->h0, m->pc_w, enc_in, T, Hg, K, H, K, H);
+        paa_gemm_desc d = gdb(m, ro(m->h0H), m->pc_w, enc_in, NOBF, T, Hg, K, H, K, H);
         d.a_kseg = Hg; d.a_kseg_stride = H; d.a_window = 1; d.a_pad = a.pos_k / 2; d.a_rows_valid = T;
         d.batch = B * G; d.batch2 = G;
         d.a_s1 = (int64_t)P * H; d.a_s2 = Hg; d.b_s1 = 0; d.b_s2 = (int64_t)Hg * K; d.c_s1 = (int64_t)P * H; d.c_s2 = Hg;
@@ -293,20 +355,22 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         d.residual = m->h0; d.ld_res = H; d.res_s1 = (int64_t)P * H; d.res_s2 = Hg;
         PAA_TRY(gemm(d, st));
     }
-    const float* x = enc_in;
+    const float* x = enc_in;          // f32 hidden state entering the layer
+    CBf xH{};                         // its bf16 planes (post-LN variant only)
     if (!a.stable_ln) {
-        PAA_TRY(layernorm_fwd(m->hsum, m->enc_ln_g, m->enc_ln_b, m->xa, m->enc_stats, M, H, a.ln_eps, nullptr, st));
-        x = m->xa;
+        PAA_TRY(layernorm_fwd(m->hsum, m->enc_ln_g, m->enc_ln_b, m->xa, m->enc_stats, M, H, a.ln_eps, m->xaH, NOBF, nullptr, st));
+        x = m->xa; xH = ro(m->xaH);
     }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < a.layers; ++l) {
         EncL& e = m->enc[l];
-        const float* attn_in = x;
+        const bool lastl = l == a.layers - 1;
+        CBf attn_in = xH;
         if (a.stable_ln) {   // x is e.ln1_in
-            PAA_TRY(layernorm_fwd(x, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, nullptr, st));
-            attn_in = m->xb;
+            PAA_TRY(layernorm_fwd(x, e.ln1_g, e.ln1_b, nullptr, e.st1, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));
+            attn_in = ro(m->xbH);
         }
-        PAA_TRY(linear(m, attn_in, e.wqkv, e.bqkv, e.qkv, M, 3 * H, H, st));
+        PAA_TRY(linear(m, attn_in, e.wqkv, e.bqkv, e.qkv, NOBF, M, 3 * H, H, st));
         {   // S = Q K^T  per (clip, head)
             paa_gemm_desc d = gd(m, e.qkv, e.qkv + H, e.P, T, T, hd, 3 * H, 3 * H, Tp);
             d.batch = B * nh; d.batch2 = nh;
@@ -315,35 +379,34 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             PAA_TRY(gemm(d, st));
         }
         PAA_TRY(softmax_fwd(e.P, B * nh, T, Tp, T, Tp, scale, st));
-        {   // ctx = P V
-            paa_gemm_desc d = gd(m, e.P, e.qkv + 2 * H, m->ctx, T, hd, T, Tp, 3 * H, H);
-            d.b_kcontig = 0;
+        {   // ctx = P V  -> bf16 planes only (operand of the output projection)
+            paa_gemm_desc d = gd(m, e.P, e.qkv + 2 * H, nullptr, T, hd, T, Tp, 3 * H, H);
+            d.b_kcontig = 0; d.Cb = m->ctxH.hi; d.Cb_lo = m->ctxH.lo;
             d.batch = B * nh; d.batch2 = nh;
             d.a_s1 = (int64_t)nh * Tp * Tp; d.a_s2 = (int64_t)Tp * Tp; d.b_s1 = (int64_t)P * 3 * H; d.b_s2 = hd;
             d.c_s1 = (int64_t)P * H; d.c_s2 = hd;
             PAA_TRY(gemm(d, st));
         }
         if (!a.stable_ln) {
-            PAA_TRY(linear(m, m->ctx, e.wo, e.bo, e.ln1_in, M, H, H, st, x));                       // r1 = x + attn
-            PAA_TRY(layernorm_fwd(e.ln1_in, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, nullptr, st));   // y1
-            PAA_TRY(linear(m, m->xb, e.w1, e.b1, m->fact, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
-            PAA_TRY(linear(m, m->fact, e.w2, e.b2, e.ln2_in, M, H, F, st, m->xb));                 // r2 = y1 + ffn
-            float* xo = (l == a.layers - 1) ? m->xfinal : m->xa;
-            PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, xo, e.st2, M, H, a.ln_eps, nullptr, st));
-            x = xo;
+            PAA_TRY(linear(m, ro(m->ctxH), e.wo, e.bo, e.ln1_in, NOBF, M, H, H, st, x));                        // r1 = x + attn
+            PAA_TRY(layernorm_fwd(e.ln1_in, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));   // y1
+            PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
+            PAA_TRY(linear(m, ro(m->factH), e.w2, e.b2, e.ln2_in, NOBF, M, H, F, st, m->xb));                   // r2 = y1 + ffn
+            if (lastl) PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, nullptr, e.st2, M, H, a.ln_eps, m->xfinalH, NOBF, nullptr, st));
+            else PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, m->xa, e.st2, M, H, a.ln_eps, m->xaH, NOBF, nullptr, st));
+            x = m->xa; xH = ro(m->xaH);
         } else {
-            PAA_TRY(linear(m, m->ctx, e.wo, e.bo, e.ln2_in, M, H, H, st, x));                       // r1 = x + attn
-            PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, m->xb, e.st2, M, H, a.ln_eps, nullptr, st));
-            PAA_TRY(linear(m, m->xb, e.w1, e.b1, m->fact, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
-            float* xo = (l == a.layers - 1) ? m->final_in : m->enc[l + 1].ln1_in;
-            PAA_TRY(linear(m, m->fact, e.w2, e.b2, xo, M, H, F, st, e.ln2_in));                     // r2 = r1 + ffn
+            PAA_TRY(linear(m, ro(m->ctxH), e.wo, e.bo, e.ln2_in, NOBF, M, H, H, st, x));                        // r1 = x + attn
+            PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, nullptr, e.st2, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));
+            PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
+            float* xo = lastl ? m->final_in : m->enc[l + 1].ln1_in;
+            PAA_TRY(linear(m, ro(m->factH), e.w2, e.b2, xo, NOBF, M, H, F, st, e.ln2_in));                      // r2 = r1 + ffn
             x = xo;
         }
     }
-    if (a.stable_ln) {
-        PAA_TRY(layernorm_fwd(x, m->enc_ln_g, m->enc_ln_b, m->xfinal, m->enc_stats, M, H, a.ln_eps, nullptr, st));
-    }
-    PAA_TRY(linear(m, m->xfinal, m->lm_w, m->lm_b, m->logits, M, V, H, st));
+    if (a.stable_ln)
+        PAA_TRY(layernorm_fwd(x, m->enc_ln_g, m->enc_ln_b, nullptr, m->enc_stats, M, H, a.ln_eps, m->xfinalH, NOBF, nullptr, st));
+    PAA_TRY(linear(m, ro(m->xfinalH), m->lm_w, m->lm_b, m->logits, NOBF, M, V, H, st));
     return PAA_OK;
 }
 
@@ -352,29 +415,24 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
     const int nc = a.n_conv, H = a.hidden, F = a.ffn, V = a.vocab, nh = a.heads, hd = H / nh, G = a.pos_groups, Hg = H / G;
     const int M = B * m->P, T = m->T, P = m->P, Tp = m->Tp;
     const float scale = 1.0f / sqrtf((float)hd);
-    // dlogits -> dx
-    float* dx = m->dxa;
-    float* dx2 = m->dxb;
-    PAA_TRY(linear(m, m->dlogits, m->lm_wt, nullptr, dx, M, H, V, st));
-    if (a.stable_ln) {
-        PAA_TRY(layernorm_bwd(dx, m->final_in, m->enc_ln_g, m->enc_stats, nullptr, nullptr, dx, M, H, st));
-    }
+    float* dx = m->dxa;   Bf dxH = m->dxaH;      // gradient of the layer output (f32 + bf16 planes)
+    float* dx2 = m->dxb;  Bf dx2H = m->dxbH;
+    PAA_TRY(linear(m, ro(m->dlogitsH), m->lm_wt, nullptr, dx, NOBF, M, H, V, st));
+    if (a.stable_ln)
+        PAA_TRY(layernorm_bwd(dx, m->final_in, m->enc_ln_g, m->enc_stats, nullptr, nullptr, dx, dxH, M, H, st));
     for (int l = a.layers - 1; l >= 0; --l) {
         EncL& e = m->enc[l];
-        const float* dattn_out;      // gradient wrt the attention block's output (= gradient of r1)
         if (!a.stable_ln) {
-            PAA_TRY(layernorm_bwd(dx, e.ln2_in, e.ln2_g, e.st2, nullptr, nullptr, dx, M, H, st));                 // dr2
-            PAA_TRY(linear(m, dx, e.w2_t, nullptr, m->dfpre, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
-            PAA_TRY(linear(m, m->dfpre, e.w1_t, nullptr, dx2, M, H, F, st, dx));                                     // dy1 = dr2 + ...
-            PAA_TRY(layernorm_bwd(dx2, e.ln1_in, e.ln1_g, e.st1, nullptr, nullptr, dx2, M, H, st));               // dr1
-            dattn_out = dx2;
-        } else {
-            PAA_TRY(linear(m, dx, e.w2_t, nullptr, m->dfpre, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
-            PAA_TRY(linear(m, m->dfpre, e.w1_t, nullptr, dx2, M, H, F, st));                                         // dn2
-            PAA_TRY(layernorm_bwd(dx2, e.ln2_in, e.ln2_g, e.st2, dx, nullptr, dx2, M, H, st));                      // dr1 = dr2 + LN2'
-            dattn_out = dx2;
+            PAA_TRY(layernorm_bwd(dx, e.ln2_in, e.ln2_g, e.st2, nullptr, nullptr, dx, dxH, M, H, st));                  // dr2
+            PAA_TRY(linear(m, ro(dxH), e.w2_t, nullptr, nullptr, m->dfpreH, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
+            PAA_TRY(linear(m, ro(m->dfpreH), e.w1_t, nullptr, dx2, NOBF, M, H, F, st, dx));                               // dy1 = dr2 + ...
+            PAA_TRY(layernorm_bwd(dx2, e.ln1_in, e.ln1_g, e.st1, nullptr, nullptr, dx2, dx2H, M, H, st));               // dr1
+        } else {   // dx = dr2 with its planes in dxH
+            PAA_TRY(linear(m, ro(dxH), e.w2_t, nullptr, nullptr, m->dfpreH, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
+            PAA_TRY(linear(m, ro(m->dfpreH), e.w1_t, nullptr, dx2, NOBF, M, H, F, st));                                   // dn2
+            PAA_TRY(layernorm_bwd(dx2, e.ln2_in, e.ln2_g, e.st2, dx, nullptr, dx2, dx2H, M, H, st));                     // dr1 = dr2 + LN2'
         }
-        PAA_TRY(linear(m, dattn_out, e.wo_t, nullptr, m->dctx, M, H, H, st));
+        PAA_TRY(linear(m, ro(dx2H), e.wo_t, nullptr, m->dctx, NOBF, M, H, H, st));
         const int64_t sq = (int64_t)P * 3 * H, sp = (int64_t)nh * Tp * Tp, sp2 = (int64_t)Tp * Tp, sc = (int64_t)P * H;
         {   // dP = dctx V^T
             paa_gemm_desc d = gd(m, m->dctx, e.qkv + 2 * H, m->dP, T, T, hd, H, 3 * H, Tp);
@@ -383,44 +441,45 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             PAA_TRY(gemm(d, st));
         }
         {   // dV = P^T dctx
-            paa_gemm_desc d = gd(m, e.P, m->dctx, m->dqkv + 2 * H, T, hd, T, Tp, H, 3 * H);
+            paa_gemm_desc d = gd(m, e.P, m->dctx, nullptr, T, hd, T, Tp, H, 3 * H);
             d.a_kcontig = 0; d.b_kcontig = 0;
+            d.Cb = m->dqkvH.hi + 2 * H; d.Cb_lo = m->dqkvH.lo ? m->dqkvH.lo + 2 * H : nullptr;
             d.batch = B * nh; d.batch2 = nh;
             d.a_s1 = sp; d.a_s2 = sp2; d.b_s1 = sc; d.b_s2 = hd; d.c_s1 = sq; d.c_s2 = hd;
             PAA_TRY(gemm(d, st));
         }
         PAA_TRY(softmax_bwd(m->dP, e.P, B * nh, T, Tp, T, Tp, scale, st));
         {   // dQ = dS K
-            paa_gemm_desc d = gd(m, m->dP, e.qkv + H, m->dqkv, T, hd, T, Tp, 3 * H, 3 * H);
-            d.b_kcontig = 0;
+            paa_gemm_desc d = gd(m, m->dP, e.qkv + H, nullptr, T, hd, T, Tp, 3 * H, 3 * H);
+            d.b_kcontig = 0; d.Cb = m->dqkvH.hi; d.Cb_lo = m->dqkvH.lo;
             d.batch = B * nh; d.batch2 = nh;
             d.a_s1 = sp; d.a_s2 = sp2; d.b_s1 = sq; d.b_s2 = hd; d.c_s1 = sq; d.c_s2 = hd;
             PAA_TRY(gemm(d, st));
         }
         {   // dK = dS^T Q
-            paa_gemm_desc d = gd(m, m->dP, e.qkv, m->dqkv + H, T, hd, T, Tp, 3 * H, 3 * H);
+            paa_gemm_desc d = gd(m, m->dP, e.qkv, nullptr, T, hd, T, Tp, 3 * H, 3 * H);
             d.a_kcontig = 0; d.b_kcontig = 0;
+            d.Cb = m->dqkvH.hi + H; d.Cb_lo = m->dqkvH.lo ? m->dqkvH.lo + H : nullptr;
             d.batch = B * nh; d.batch2 = nh;
             d.a_s1 = sp; d.a_s2 = sp2; d.b_s1 = sq; d.b_s2 = hd; d.c_s1 = sq; d.c_s2 = hd;
             PAA_TRY(gemm(d, st));
         }
         if (!a.stable_ln) {
-            PAA_TRY(linear(m, m->dqkv, e.wqkv_t, nullptr, dx, M, H, 3 * H, st, dattn_out));       // dx = dr1 + dqkv Wqkv
+            PAA_TRY(linear(m, ro(m->dqkvH), e.wqkv_t, nullptr, dx, NOBF, M, H, 3 * H, st, dx2));          // dx = dr1 + dqkv Wqkv
         } else {
-            PAA_TRY(linear(m, m->dqkv, e.wqkv_t, nullptr, dx, M, H, 3 * H, st));                  // dn1
-            PAA_TRY(layernorm_bwd(dx, e.ln1_in, e.ln1_g, e.st1, dattn_out, nullptr, dx, M, H, st));   // dx = dr1 + LN1'
+            PAA_TRY(linear(m, ro(m->dqkvH), e.wqkv_t, nullptr, dx, NOBF, M, H, 3 * H, st));               // dn1
+            PAA_TRY(layernorm_bwd(dx, e.ln1_in, e.ln1_g, e.st1, dx2, nullptr, dx, dxH, M, H, st));        // dx = dr1 + LN1'
         }
     }
-    if (!a.stable_ln) {
-        PAA_TRY(layernorm_bwd(dx, m->hsum, m->enc_ln_g, m->enc_stats, nullptr, nullptr, dx, M, H, st));   // d hsum
-    }
+    if (!a.stable_ln)
+        PAA_TRY(layernorm_bwd(dx, m->hsum, m->enc_ln_g, m->enc_stats, nullptr, nullptr, dx, NOBF, M, H, st));   // d hsum
     // ---- positional conv backward: dh0 = dhsum + convT(dhsum * gelu'(pos_pre)) ----
     hipLaunchKernelGGL(k_mul_gelu_grad, dim3(std::min(cdiv((int64_t)M * H, 256), 4096)), dim3(256), 0, st, (const float*)dx,
-                       (const float*)m->pos_pre, m->dpos, (int64_t)M * H);
+                       (const float*)m->pos_pre, (float*)nullptr, m->dposH, (int64_t)M * H);
     PAA_LAUNCH_CHECK();
     {
         const int K = a.pos_k * Hg;
-        paa_gemm_desc d = gd(m, m->dpos, m->pc_wd, m->dh0, T, Hg, K, H, K, H);
+        paa_gemm_desc d = gdb(m, ro(m->dposH), m->pc_wd, m->dh0, m->dh0H, T, Hg, K, H, K, H);
         d.a_kseg = Hg; d.a_kseg_stride = H; d.a_window = 1; d.a_pad = a.pos_k - 1 - a.pos_k / 2; d.a_rows_valid = T;
         d.batch = B * G; d.batch2 = G;
         d.a_s1 = (int64_t)P * H; d.a_s2 = Hg; d.b_s1 = 0; d.b_s2 = (int64_t)Hg * K; d.c_s1 = (int64_t)P * H; d.c_s2 = Hg;
@@ -429,31 +488,36 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
     }
     // ---- feature projection backward ----
     const ConvL& cl = m->conv[nc - 1];
-    PAA_TRY(linear(m, m->dh0, m->fp_wt, nullptr, m->dfn, M, cl.cout, H, st));
-    // gradient wrt conv_{last}'s GELU output, then through the GELU
-    float* gz = m->gbuf[(nc - 1) & 1];
-    PAA_TRY(layernorm_bwd(m->dfn, cl.act, m->fp_ln_g, m->fp_stats, nullptr, nullptr, gz, M, cl.cout, st));
-    hipLaunchKernelGGL(k_mul_gelu_grad, dim3(std::min(cdiv((int64_t)M * cl.cout, 256), 4096)), dim3(256), 0, st,
-                       (const float*)gz, (const float*)cl.pre, gz, (int64_t)M * cl.cout);
-    PAA_LAUNCH_CHECK();
+    PAA_TRY(linear(m, ro(m->dh0H), m->fp_wt, nullptr, m->dfn, NOBF, M, cl.cout, H, st));
+    // gradient wrt conv_{last}'s GELU output, then through the GELU -> gradient wrt its norm output
+    PAA_TRY(layernorm_bwd(m->dfn, cl.act_f, m->fp_ln_g, m->fp_stats, nullptr, nullptr, m->gz, NOBF, M, cl.cout, st));
+    {
+        const int j = (nc - 1) & 1;
+        hipLaunchKernelGGL(k_mul_gelu_grad, dim3(std::min(cdiv((int64_t)M * cl.cout, 256), 4096)), dim3(256), 0, st,
+                           (const float*)m->gz, (const float*)cl.pre, a.feat_norm_layer ? m->gF[j] : (float*)nullptr,
+                           a.feat_norm_layer ? NOBF : m->gH[j], (int64_t)M * cl.cout);
+        PAA_LAUNCH_CHECK();
+    }
     // ---- feature encoder backward ----
     for (int i = nc - 1; i >= 1; --i) {
         ConvL& c = m->conv[i];
         const ConvL& pr = m->conv[i - 1];
-        float* gin = m->gbuf[i & 1];           // gradient wrt layer i's norm output (pre-GELU)
-        float* gout = m->gbuf[(i - 1) & 1];
-        if (a.feat_norm_layer)                 // through LayerNorm_i to the raw conv output
-            PAA_TRY(layernorm_bwd(gin, c.cv, c.g, c.row_stats, nullptr, nullptr, gin, B * c.P, c.cout, st));
+        const int ji = i & 1, jo = (i - 1) & 1;
+        if (a.feat_norm_layer)                 // through LayerNorm_i to the raw conv output (f32 in, bf16 planes out)
+            PAA_TRY(layernorm_bwd(m->gF[ji], c.cv, c.g, c.row_stats, nullptr, nullptr, nullptr, m->gH[ji], B * c.P, c.cout, st));
+        const bool out_f32 = a.feat_norm_layer || i == 1;     // next consumer is an element-wise kernel
         for (int rho = 0; rho < c.s; ++rho) {
             const int Q = c.wdQ[rho];
             const int64_t ldo = (int64_t)c.s * c.cin;
             if (Q < 0) {   // no tap reaches this residue class: zero gradient rows
-                PAA_HIP(hipMemset2DAsync(gout + (int64_t)rho * c.cin, ldo * 4, 0, (size_t)c.cin * 4, (size_t)B * c.P, st));
+                if (out_f32) PAA_HIP(hipMemset2DAsync(m->gF[jo] + (int64_t)rho * c.cin, ldo * 4, 0, (size_t)c.cin * 4, (size_t)B * c.P, st));
+                else PAA_HIP(hipMemset2DAsync(m->gH[jo].hi + (int64_t)rho * c.cin, ldo * 2, 0, (size_t)c.cin * 2, (size_t)B * c.P, st));
                 continue;
             }
             const int K = (Q + 1) * c.cout;
-            paa_gemm_desc d = gd(m, gin - (int64_t)Q * c.cout, c.wd[rho], gout + (int64_t)rho * c.cin, B * c.P, c.cin, K,
-                                 c.cout, K, ldo);
+            paa_gemm_desc d = gdb(m, ro(m->gH[ji]).off(-(int64_t)Q * c.cout), c.wd[rho], nullptr, NOBF, B * c.P, c.cin, K, c.cout, K, ldo);
+            if (out_f32) d.C = m->gF[jo] + (int64_t)rho * c.cin;
+            else { Bf o = boff(m->gH[jo], (int64_t)rho * c.cin); d.Cb = o.hi; d.Cb_lo = o.lo; }
             d.act = PAA_ACT_GELU_GRAD; d.aux = pr.pre + (int64_t)rho * c.cin; d.ld_aux = ldo;
             PAA_TRY(gemm(d, st));
         }
@@ -462,8 +526,8 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
         ConvL& c = m->conv[0];
         Conv0Args ca{};
         ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
-        ca.k = c.k; ca.stride = c.s; ca.w = c.w; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
-        ca.gn_stats = m->gn_stats; ca.gn_bsums = m->gn_bsums; ca.row_stats = c.row_stats; ca.dpre = m->gbuf[0]; ca.G = m->G;
+        ca.k = c.k; ca.stride = c.s; ca.w = c.w0; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
+        ca.gn_stats = m->gn_stats; ca.gn_bsums = m->gn_bsums; ca.row_stats = c.row_stats; ca.dpre = m->gF[0]; ca.G = m->G;
         PAA_TRY(conv0_backward(ca, a.feat_norm_layer, m->c0_part, grad, st));
     }
     return PAA_OK;
@@ -487,7 +551,7 @@ extern "C" paa_status paa_model_fwd_bwd(paa_model* m, const float* d_clean, cons
     }
     if (d_labels) {
         PAA_TRY(ctc(m->logits, d_labels, B, m->T, m->P, V, S_max, m->a.blank, (float)direction, m->nll,
-                    d_grad ? m->dlogits : nullptr, m->ctc_work, st));
+                    d_grad ? m->dlogits : nullptr, d_grad ? m->dlogitsH : NOBF, m->ctc_work, st));
         if (d_stats) PAA_TRY(sum_small(m->nll, B, d_stats, st));
     }
     if (d_grad) PAA_TRY(backward(m, d_clean, d_p, clamp, B, d_grad, st));
@@ -502,9 +566,9 @@ extern "C" void paa_abi_sizes(int32_t* out4) {
     out4[3] = (int32_t)sizeof(paa_gemm_desc);
 }
 
-// Test/diagnostic access to the internal activations (synchronous copy to host; never on the step path).
-// Names: conv{i}.pre|act|cv, fn, h0, pos_pre, hsum, xfinal, logits, dlogits, nll, G, gbuf0, gbuf1, dh0, dfn, dxa,
-//        L{l}.qkv|P|ln1_in|fpre|ln2_in.  Returns the number of floats available (0 if unknown).
+// Test/diagnostic access to the internal activations (synchronous copy to host as f32; never on the step path).
+// f32 buffers: conv{i}.pre, conv{last}.act, conv{i}.cv, h0, pos_pre, hsum, logits, dlogits, nll, G, gbuf0, dh0, dfn, dxa,
+//              gn_stats, L{l}.qkv|P|ln1_in|fpre|ln2_in.   bf16 planes (hi + lo summed): conv{i}.act (i < last), fn, xfinal.
 extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* host, int64_t max_floats, int B) {
     if (!m || !name) return 0;
     const std::string n(name);
@@ -512,16 +576,17 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
     const int nc = a.n_conv, H = a.hidden, F = a.ffn, V = a.vocab;
     const int64_t M = (int64_t)B * m->P;
     const float* p = nullptr;
+    Bf pb = NOBF;
     int64_t cnt = 0;
-    for (int i = 0; i < nc && !p; ++i) {
+    for (int i = 0; i < nc && !p && !pb.hi; ++i) {
         const ConvL& c = m->conv[i];
         const std::string b = "conv" + std::to_string(i);
         const int64_t sz = (int64_t)B * c.P * c.cout;
         if (n == b + ".pre") { p = c.pre; cnt = sz; }
-        else if (n == b + ".act") { p = c.act; cnt = sz; }
+        else if (n == b + ".act") { if (c.act_f) p = c.act_f; else pb = c.actb; cnt = sz; }
         else if (n == b + ".cv" && c.cv) { p = c.cv; cnt = sz; }
     }
-    for (int l = 0; l < a.layers && !p; ++l) {
+    for (int l = 0; l < a.layers && !p && !pb.hi; ++l) {
         const EncL& e = m->enc[l];
         const std::string b = "L" + std::to_string(l);
         if (n == b + ".qkv") { p = e.qkv; cnt = M * 3 * H; }
@@ -530,30 +595,41 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
         else if (n == b + ".fpre") { p = e.fpre; cnt = M * F; }
         else if (n == b + ".ln2_in") { p = e.ln2_in; cnt = M * H; }
     }
-    if (!p) {
+    if (!p && !pb.hi) {
         const ConvL& c0 = m->conv[0];
-        int maxC = 0;
-        for (int i = 0; i < nc; ++i) maxC = std::max(maxC, a.conv_dim[i]);
-        if (n == "fn") { p = m->fn; cnt = M * a.conv_dim[nc - 1]; }
+        if (n == "fn") { pb = m->fnH; cnt = M * a.conv_dim[nc - 1]; }
         else if (n == "h0") { p = m->h0; cnt = M * H; }
         else if (n == "pos_pre") { p = m->pos_pre; cnt = M * H; }
         else if (n == "hsum") { p = a.stable_ln ? m->enc[0].ln1_in : m->hsum; cnt = M * H; }
-        else if (n == "xfinal") { p = m->xfinal; cnt = M * H; }
+        else if (n == "xfinal") { pb = m->xfinalH; cnt = M * H; }
         else if (n == "logits") { p = m->logits; cnt = M * V; }
         else if (n == "dlogits") { p = m->dlogits; cnt = M * V; }
         else if (n == "nll") { p = m->nll; cnt = B; }
         else if (n == "G") { p = m->G; cnt = (int64_t)B * c0.P * c0.k; }
-        else if (n == "gbuf0") { p = m->gbuf[0]; cnt = (int64_t)B * c0.P * maxC; }
-        else if (n == "gbuf1") { p = m->gbuf[1]; cnt = (int64_t)B * c0.P * maxC; }
+        else if (n == "gbuf0") { p = m->gF[0]; cnt = (int64_t)B * c0.P * c0.cout; }
         else if (n == "dh0") { p = m->dh0; cnt = M * H; }
         else if (n == "dfn") { p = m->dfn; cnt = M * a.conv_dim[nc - 1]; }
         else if (n == "dxa") { p = m->dxa; cnt = M * H; }
         else if (n == "gn_stats") { p = m->gn_stats; cnt = (int64_t)B * c0.cout * 2; }
     }
-    if (!p) return 0;
+    if (!p && !pb.hi) return 0;
     if (host && max_floats > 0) {
+        const int64_t nn = std::min(cnt, max_floats);
         if (hipDeviceSynchronize() != hipSuccess) return -1;
-        if (hipMemcpy(host, p, sizeof(float) * std::min(cnt, max_floats), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (p) {
+            if (hipMemcpy(host, p, sizeof(float) * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        } else {
+            std::vector<unsigned short> hi(nn), lo(pb.lo ? nn : 0);
+            if (hipMemcpy(hi.data(), pb.hi, 2 * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            if (pb.lo && hipMemcpy(lo.data(), pb.lo, 2 * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            for (int64_t i = 0; i < nn; ++i) {
+                uint32_t u = (uint32_t)hi[i] << 16;
+                float v;
+                memcpy(&v, &u, 4);
+                if (pb.lo) { uint32_t u2 = (uint32_t)lo[i] << 16; float v2; memcpy(&v2, &u2, 4); v += v2; }
+                host[i] = v;
+            }
+        }
     }
     return cnt;
 }

@@ -9,10 +9,12 @@ namespace paa {
 
 paa_status gemm(const paa_gemm_desc& d, hipStream_t st);
 
+// y (f32, optional), yb = bf16 planes of y (optional), actb / yact = gelu(y) as bf16 planes / f32 (optional)
 paa_status layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats, int rows, int cols,
-                         float eps, float* y_act /* optional gelu(y) */, hipStream_t st);
+                         float eps, Bf yb, Bf actb, float* yact, hipStream_t st);
+// dx (f32, optional; may alias dy), dxb = bf16 planes of dx (optional)
 paa_status layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, const float* add,
-                         const float* gelu_pre, float* dx, int rows, int cols, hipStream_t st);
+                         const float* gelu_pre, float* dx, Bf dxb, int rows, int cols, hipStream_t st);
 // n_mat matrices of rows_per_mat valid rows (mat_rows_ld allocated rows each), `cols` valid columns, row stride ld
 paa_status softmax_fwd(float* s, int n_mat, int rows_per_mat, int mat_rows_ld, int cols, int ld, float scale,
                        hipStream_t st);
@@ -31,7 +33,7 @@ struct Conv0Args {
     const float* beta;
     float eps;
     float* pre;              // (B, P, C) norm output (pre-GELU)
-    float* act;              // (B, P, C) GELU(pre)
+    Bf actb;                 // (B, P, C) GELU(pre) as bf16 planes (the next conv's GEMM operand)
     float* gn_stats;         // group: (B, C, 2) mean, rstd over time
     float* gn_bsums;         // group backward: (B, C, 2) mean_t(dy), mean_t(dy * xhat)
     float* row_stats;        // layer: (B, P, 2) mean, rstd over channels
@@ -46,7 +48,7 @@ int conv0_chunks(int T);
 
 int64_t ctc_work_floats_per_clip(int T, int V, int S_max);
 paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
-               float grad_scale, float* nll, float* dlogits, float* work, hipStream_t st);
+               float grad_scale, float* nll, float* dlogits, Bf dlb, float* work, hipStream_t st);
 paa_status sum_small(const float* x, int n, float* out, hipStream_t st);
 
 }  // namespace paa

@@ -13,8 +13,8 @@ namespace paa {
 // One wave per row; rows are short (<= 4 KB) and stay in L1 across the passes.
 __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ g,
                                               const float* __restrict__ b, float* __restrict__ y,
-                                              float* __restrict__ stats, int rows, int cols, float eps, int gelu,
-                                              float* __restrict__ y_act) {
+                                              float* __restrict__ stats, int rows, int cols, float eps, Bf yb, Bf actb,
+                                              float* __restrict__ yact) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -37,16 +37,21 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
         const float4 v = *reinterpret_cast<const float4*>(xr + c);
         const float4 gg = *reinterpret_cast<const float4*>(g + c);
         const float4 bv = *reinterpret_cast<const float4*>(b + c);
-        float4 o;
-        o.x = (v.x - mean) * rstd * gg.x + bv.x;
-        o.y = (v.y - mean) * rstd * gg.y + bv.y;
-        o.z = (v.z - mean) * rstd * gg.z + bv.z;
-        o.w = (v.w - mean) * rstd * gg.w + bv.w;
-        *reinterpret_cast<float4*>(y + (size_t)row * cols + c) = o;
-        if (gelu) {
-            float4 a;
-            a.x = gelu_f(o.x); a.y = gelu_f(o.y); a.z = gelu_f(o.z); a.w = gelu_f(o.w);
-            *reinterpret_cast<float4*>(y_act + (size_t)row * cols + c) = a;
+        float o[4];
+        o[0] = (v.x - mean) * rstd * gg.x + bv.x;
+        o[1] = (v.y - mean) * rstd * gg.y + bv.y;
+        o[2] = (v.z - mean) * rstd * gg.z + bv.z;
+        o[3] = (v.w - mean) * rstd * gg.w + bv.w;
+        const size_t i0 = (size_t)row * cols + c;
+        if (y) *reinterpret_cast<float4*>(y + i0) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            store_bf16(yb, i0 + j, o[j]);
+            if (actb.hi || yact) {
+                const float ga = gelu_f(o[j]);
+                store_bf16(actb, i0 + j, ga);
+                if (yact) yact[i0 + j] = ga;
+            }
         }
     }
 }
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
                                               const float* __restrict__ g, const float* __restrict__ stats,
                                               const float* __restrict__ add, const float* __restrict__ gelu_pre,
-                                              float* __restrict__ dx, int rows, int cols) {
+                                              float* __restrict__ dx, int rows, int cols, Bf dxb) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -77,22 +82,22 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
         const float xh = (x[o + c] - mean) * rstd;
         float v = rstd * (g[c] * d - s1 - xh * s2);
         if (add) v += add[o + c];
-        dx[o + c] = v;
+        if (dx) dx[o + c] = v;
+        store_bf16(dxb, o + c, v);
     }
 }
 
 paa_status layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats, int rows, int cols,
-                         float eps, float* y_act, hipStream_t st) {
+                         float eps, Bf yb, Bf actb, float* yact, hipStream_t st) {
     if (cols & 3) PAA_FAIL(PAA_ERR_ARG, "layernorm: cols=%d must be a multiple of 4", cols);
-    hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, g, b, y, stats, rows, cols, eps,
-                       y_act ? 1 : 0, y_act);
+    hipLaunchKernelGGL(k_ln_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, g, b, y, stats, rows, cols, eps, yb, actb, yact);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
 
 paa_status layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, const float* add,
-                         const float* gelu_pre, float* dx, int rows, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, g, stats, add, gelu_pre, dx, rows, cols);
+                         const float* gelu_pre, float* dx, Bf dxb, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, g, stats, add, gelu_pre, dx, rows, cols, dxb);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
             } else if (MODE == 1) {
                 const float y = (v - mean) * rstd * gam + bet;
                 a.pre[o] = y;
-                a.act[o] = gelu_f(y);
+                store_bf16(a.actb, o, gelu_f(y));
             } else {
                 const float dy = a.dpre[o];
                 s1 += dy; s2 += dy * ((v - mean) * rstd);
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
         for (int t = a.T; t < a.P; ++t)
             for (int c = threadIdx.x; c < a.C; c += 256) {
                 const size_t o = ((size_t)b * a.P + t) * a.C + c;
-                a.pre[o] = 0.f; a.act[o] = 0.f;
+                a.pre[o] = 0.f; store_bf16(a.actb, o, 0.f);
             }
 }
 
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256) void k_conv0_rows(Conv0Args a) {
         const size_t row = (size_t)b * a.P + t;
         if (t >= a.T) {                       // pad rows
             if (MODE == C0_FWD_LN) {
-                for (int i = 0; i < nc; ++i) { const int c = lane + 64 * i; if (c < a.C) { a.pre[row * a.C + c] = 0.f; a.act[row * a.C + c] = 0.f; } }
+                for (int i = 0; i < nc; ++i) { const int c = lane + 64 * i; if (c < a.C) { a.pre[row * a.C + c] = 0.f; store_bf16(a.actb, row * a.C + c, 0.f); } }
                 if (lane == 0) { a.row_stats[2 * row] = 0.f; a.row_stats[2 * row + 1] = 0.f; }
             } else if (lane < a.k) a.G[row * a.k + lane] = 0.f;
             continue;
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256) void k_conv0_rows(Conv0Args a) {
                     if (i < nc && c < a.C) {
                         const float y = (v[i] - mean) * rstd * gam[i] + bet[i];
                         a.pre[row * a.C + c] = y;
-                        a.act[row * a.C + c] = gelu_f(y);
+                        store_bf16(a.actb, row * a.C + c, gelu_f(y));
                     }
                 }
                 continue;
@@ -442,7 +447,7 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
 __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                            int T, int Tpad, int V, int S_max, int blank, float gscale,
                                            float* __restrict__ nll_out, float* __restrict__ dlogits,
-                                           float* __restrict__ work, int64_t work_per_clip) {
+                                           float* __restrict__ work, int64_t work_per_clip, Bf dlb) {
     extern __shared__ __attribute__((aligned(16))) double smd[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int SPmax = 2 * S_max + 1;
@@ -521,9 +526,10 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
     if (!dlogits) return;
     const double nll = s_nll;
     float* dl = dlogits + (size_t)b * Tpad * V;
-    for (int i = tid; i < (Tpad - T) * V; i += 256) dl[(size_t)T * V + i] = 0.f;     // pad frames
+    const size_t dlo = (size_t)b * Tpad * V;
+    for (int i = tid; i < (Tpad - T) * V; i += 256) { dl[(size_t)T * V + i] = 0.f; store_bf16(dlb, dlo + (size_t)T * V + i, 0.f); }   // pad frames
     if (!(nll < INFINITY)) {      // infeasible alignment: zero_infinity=False propagates non-finite gradients
-        for (int i = tid; i < T * V; i += 256) dl[i] = NAN;
+        for (int i = tid; i < T * V; i += 256) { dl[i] = NAN; store_bf16(dlb, dlo + i, NAN); }
         return;
     }
     // phase 3: beta + gradient.  beta_{T-1}: last blank and last label.
@@ -554,8 +560,11 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
             if (q) atomicAdd(&occ[l], q);
         }
         __syncthreads();
-        for (int c = tid; c < V; c += 256)
-            dl[(size_t)t * V + c] = gscale * (float)(exp(lp[(size_t)t * V + c]) - (double)occ[c] * (1.0 / 1073741824.0));
+        for (int c = tid; c < V; c += 256) {
+            const float gv = gscale * (float)(exp(lp[(size_t)t * V + c]) - (double)occ[c] * (1.0 / 1073741824.0));
+            dl[(size_t)t * V + c] = gv;
+            store_bf16(dlb, dlo + (size_t)t * V + c, gv);
+        }
         __syncthreads();
     }
 }
@@ -566,14 +575,14 @@ int conv0_chunks(int T) { return cdiv(T, C0_TCH); }
 int64_t ctc_work_floats_per_clip(int T, int V, int S_max) { return 2 * ((int64_t)T * V + (int64_t)T * (2 * S_max + 1)); }
 
 paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
-               float grad_scale, float* nll, float* dlogits, float* work, hipStream_t st) {
+               float grad_scale, float* nll, float* dlogits, Bf dlb, float* work, hipStream_t st) {
     if (S_max < 1 || S_max > 4000) PAA_FAIL(PAA_ERR_SIZE, "ctc: S_max=%d out of range", S_max);
     if (V > 256) PAA_FAIL(PAA_ERR_SIZE, "ctc: vocab %d > 256", V);
     if ((uintptr_t)work & 7) PAA_FAIL(PAA_ERR_ARG, "ctc: work buffer must be 8-byte aligned");
     const int SPmax = 2 * S_max + 1;
     const size_t lds = sizeof(double) * 2 * (size_t)SPmax + sizeof(int) * ((size_t)SPmax + V);
     hipLaunchKernelGGL(k_ctc, dim3(B), dim3(256), lds, st, logits, labels, T, Tpad, V, S_max, blank, grad_scale, nll,
-                       dlogits, work, ctc_work_floats_per_clip(T, V, S_max) / 2);
+                       dlogits, work, ctc_work_floats_per_clip(T, V, S_max) / 2, dlb);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
@@ -598,11 +607,11 @@ using namespace paa;
 
 extern "C" paa_status paa_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats,
                                         int rows, int cols, float eps, void* stream) {
-    return layernorm_fwd(x, g, b, y, stats, rows, cols, eps, nullptr, (hipStream_t)stream);
+    return layernorm_fwd(x, g, b, y, stats, rows, cols, eps, Bf{nullptr, nullptr}, Bf{nullptr, nullptr}, nullptr, (hipStream_t)stream);
 }
 extern "C" paa_status paa_layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, float* dx,
                                         int rows, int cols, void* stream) {
-    return layernorm_bwd(dy, x, g, stats, nullptr, nullptr, dx, rows, cols, (hipStream_t)stream);
+    return layernorm_bwd(dy, x, g, stats, nullptr, nullptr, dx, Bf{nullptr, nullptr}, rows, cols, (hipStream_t)stream);
 }
 extern "C" paa_status paa_softmax_fwd(float* s, int rows, int cols, int ld, float scale, void* stream) {
     return softmax_fwd(s, 1, rows, rows, cols, ld, scale, (hipStream_t)stream);
@@ -613,5 +622,5 @@ extern "C" paa_status paa_softmax_bwd(float* dp, const float* p, int rows, int c
 extern "C" int64_t paa_ctc_work_floats(int B, int T, int V, int S_max) { return (int64_t)B * ctc_work_floats_per_clip(T, V, S_max); }
 extern "C" paa_status paa_ctc(const float* logits, const int32_t* labels, int B, int T, int V, int S_max, int blank,
                               float grad_scale, float* nll, float* dlogits, float* work, void* stream) {
-    return ctc(logits, labels, B, T, T, V, S_max, blank, grad_scale, nll, dlogits, work, (hipStream_t)stream);
+    return ctc(logits, labels, B, T, T, V, S_max, blank, grad_scale, nll, dlogits, Bf{nullptr, nullptr}, work, (hipStream_t)stream);
 }

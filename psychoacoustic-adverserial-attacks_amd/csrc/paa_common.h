@@ -68,6 +68,21 @@ __device__ __forceinline__ T block_sum(T v, T* sm) {
     return r;
 }
 
+// bf16 planes: hi = bf16(v) and, in split (fp32-parity) mode, lo = bf16(v - hi).  Either pointer may be null.
+struct Bf {
+    unsigned short* hi;
+    unsigned short* lo;
+};
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ void store_bf16(const Bf& o, size_t i, float v) {
+    if (o.hi) {
+        const unsigned short h = bf16_bits(v);
+        o.hi[i] = h;
+        if (o.lo) o.lo[i] = bf16_bits(v - bf16_to_f32(h));
+    }
+}
+
 // exact (erf) GELU and its derivative, as torch.nn.functional.gelu(approximate='none')
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

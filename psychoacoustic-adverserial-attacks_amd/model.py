@@ -86,6 +86,31 @@ def pack_weights(a: Wav2Vec2Arch, sd: dict) -> dict:
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()}
 
 
+def is_gemm_weight(name: str) -> bool:
+    """Packed tensors that are GEMM B operands (stored as bf16 planes on the device); the rest stay f32."""
+    if name == "c0.w":
+        return False
+    leaf = name.split(".", 1)[1]
+    return leaf in ("w", "wt", "wd", "wqkv", "wqkv_t", "wo", "wo_t", "w1", "w1_t", "w2", "w2_t") or leaf.startswith("wd")
+
+
+def bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns, round-to-nearest-even (what v_cvt_pk_bf16_f32 does for finite values)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def split_bf16(x: np.ndarray):
+    """x ~= hi + lo with both bf16: the operand planes of the fp32-parity (3-pass) GEMM."""
+    hi = bf16_bits(x)
+    lo = bf16_bits(np.asarray(x, dtype=np.float32) - bf16_to_f32(hi))
+    return hi, lo
+
+
 def arch_struct(a: Wav2Vec2Arch) -> _lib.PaaArch:
     s = _lib.PaaArch()
     s.n_conv = len(a.conv_dim)
@@ -126,23 +151,34 @@ class PaaModel:
         if self.device.type != "cuda":
             raise RuntimeError("PaaModel needs a GPU; there is no CPU fallback")
         packed = pack_weights(arch, state_dict)
-        # one device buffer for all packed weights, 256-byte aligned slices
+        # GEMM weights become bf16 planes (hi, and lo for the fp32-parity mode); everything else stays f32
+        planes = {}
+        for k, v in packed.items():
+            if is_gemm_weight(k):
+                hi, lo = split_bf16(v)
+                planes[k] = hi
+                if dtype == "fp32":
+                    planes[k + ".lo"] = lo
+            else:
+                planes[k] = v
+        # one device byte buffer for all packed weights, 256-byte aligned slices
         offs, total = {}, 0
-        for k, v in packed.items():
+        for k, v in planes.items():
             offs[k] = total
-            total += (v.size + 63) // 64 * 64
-        host = np.zeros(total, dtype=np.float32)
-        for k, v in packed.items():
-            host[offs[k]:offs[k] + v.size] = v.reshape(-1)
+            total += (v.nbytes + 255) // 256 * 256
+        host = np.zeros(total, dtype=np.uint8)
+        for k, v in planes.items():
+            host[offs[k]:offs[k] + v.nbytes] = v.reshape(-1).view(np.uint8)
         self._weights = torch.from_numpy(host).to(self.device)
-        names = [k.encode() for k in packed]
-        arr = (_lib.PaaTensor * len(packed))()
+        names = [k.encode() for k in planes]
+        arr = (_lib.PaaTensor * len(planes))()
         base = self._weights.data_ptr()
-        for i, (k, v) in enumerate(packed.items()):
+        for i, (k, v) in enumerate(planes.items()):
             arr[i].name = names[i]
-            arr[i].d_ptr = base + 4 * offs[k]
+            arr[i].d_ptr = base + offs[k]
             arr[i].numel = v.size
         self._names = names
+        packed = planes
         h = C.c_void_p()
         st = arch_struct(arch)
         with torch.cuda.device(self.device):

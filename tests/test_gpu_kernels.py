@@ -106,6 +106,69 @@ def test_gemm_gelu_grad_residual_accumulate(prec):
           dict(A=M * K, B=N * K, C=M * 2 * N, aux=M * 2 * N, residual=M * N), prec, offs=dict(C=N, aux=N))
 
 
+def _bf_case(name, d, shapes, prec, seed=0, offs=None):
+    """bf16-operand path: A / B are bf16 planes (hi [+ lo]); the reference multiplies exactly those values."""
+    from paa_amd.model import bf16_to_f32, split_bf16
+    rng = np.random.default_rng(seed)
+    host = {k: rng.normal(size=n).astype(np.float32) for k, n in shapes.items()}
+    host["C"][:] = 0
+    bufs, ref = {}, {}
+    for k, v in host.items():
+        if k in ("A", "B"):
+            hi, lo = split_bf16(v)
+            bufs[k] = torch.from_numpy(hi.view(np.int16)).cuda()
+            bufs[k + "_lo"] = torch.from_numpy(lo.view(np.int16)).cuda()
+            ref[k] = (bf16_to_f32(hi).astype(np.float64) + (bf16_to_f32(lo).astype(np.float64) if prec else 0.0))
+        else:
+            bufs[k] = dev(v)
+            ref[k] = v.astype(np.float64)
+    cb = torch.zeros(shapes["C"], dtype=torch.int16, device="cuda")
+    cbl = torch.zeros(shapes["C"], dtype=torch.int16, device="cuda")
+    bufs["Cb"], bufs["Cb_lo"] = cb, cbl
+    dd = dict(d)
+    dd.update(precision=prec, operand_bf16=1)
+    names = {k: k for k in shapes}
+    names.update(Cb="Cb")
+    if prec:
+        names.update(A_lo="A_lo", B_lo="B_lo", Cb_lo="Cb_lo")
+    run_gemm({**dd, **names}, bufs, offs)
+    o = offs or {}
+    de = {k: v for k, v in dd.items() if k != "operand_bf16"}
+    emulate(de, ref["A"], ref["B"], ref["C"], a_off=o.get("A", 0), b_off=o.get("B", 0), c_off=o.get("C", 0),
+            bias=ref.get("bias"), aux=ref.get("aux"), aux_off=o.get("aux", 0), residual=ref.get("residual"),
+            res_off=o.get("residual", 0), C_pre=ref.get("C_pre"))
+    e = rel_err(bufs["C"].cpu().numpy(), ref["C"])
+    got_b = bf16_to_f32(cb.cpu().numpy().view(np.uint16)).astype(np.float64)
+    if prec:
+        got_b = got_b + bf16_to_f32(cbl.cpu().numpy().view(np.uint16))
+    eb = rel_err(got_b, ref["C"])
+    print(f"gemm_bf[{name}] prec={prec} rel_err={e:.3e} bf16-planes rel_err={eb:.3e}")
+    assert e < (3e-5 if prec else 5e-6), name
+    assert eb < (3e-5 if prec else 5e-3), name
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_bf16_operands(prec):
+    M, N, K = 300, 200, 96
+    _bf_case("plain", dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, act=1), dict(A=M * K, B=N * K, C=M * N, bias=N, C_pre=M * N), prec)
+    M, N, K = 257, 384, 1536
+    _bf_case("bigk", dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N), dict(A=M * K, B=N * K, C=M * N), prec)
+    Cc, k, s, M = 32, 3, 2, 250
+    _bf_case("convview", dict(M=M, N=Cc, K=k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Cc, row_period=50, row_valid=49, act=1),
+             dict(A=(s * M + 8) * Cc, B=Cc * k * Cc, C=M * Cc, C_pre=M * Cc), prec)
+    _bf_case("n32k40", dict(M=200, N=32, K=40, lda=40, ldb=40, ldc=32), dict(A=200 * 40, B=32 * 40, C=200 * 32, bias=32), prec)
+    B, G, Hg, Kt, T, P = 2, 4, 16, 16, 40, 41
+    H = G * Hg
+    d = dict(M=T, N=Hg, K=Kt * Hg, lda=H, ldb=Kt * Hg, ldc=H, a_kseg=Hg, a_kseg_stride=H, a_window=1, a_pad=Kt // 2,
+             a_rows_valid=T, batch=B * G, batch2=G, a_s1=P * H, a_s2=Hg, b_s2=Hg * Kt * Hg, c_s1=P * H, c_s2=Hg,
+             bias_s2=Hg, act=1, ld_res=H, res_s1=P * H, res_s2=Hg)
+    _bf_case("window", d, dict(A=B * P * H, B=G * Hg * Kt * Hg, C=B * P * H, bias=H, C_pre=B * P * H, residual=B * P * H), prec)
+    # dgrad form: A rows start Q rows back (guard rows), output rows interleaved (ldc = 2 N), gelu' epilogue
+    Mr, Co, Ci = 120, 32, 32
+    _bf_case("dgrad", dict(M=Mr, N=Ci, K=2 * Co, lda=Co, ldb=2 * Co, ldc=2 * Ci, act=2, ld_aux=2 * Ci),
+             dict(A=(Mr + 8) * Co, B=Ci * 2 * Co, C=Mr * 2 * Ci, aux=Mr * 2 * Ci), prec, offs=dict(A=7 * Co, C=Ci, aux=Ci))
+
+
 def test_layernorm_fwd_bwd():
     torch.manual_seed(0)
     for rows, cols in ((37, 512), (130, 768), (9, 64), (5, 32)):
