@@ -27,8 +27,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VARIANTS = {v: f"k_gemm<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'},A{'k' if v & 2 else 'm'},B{'k' if v & 1 else 'n'}>"
-            for v in range(16)}
+VARIANTS = {v: (f"k_gemm_bf<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'}>" if v & 16 else
+                f"k_gemm<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'},A{'k' if v & 2 else 'm'},B{'k' if v & 1 else 'n'}>")
+            for v in range(32)}
 
 
 def parse():
@@ -169,10 +170,10 @@ def main():
 
     roofline = None
     if prof_on:
-        out = (C.c_double * 48)()
+        out = (C.c_double * 96)()
         _lib.check(_lib.lib().paa_prof_read(out))
         _lib.lib().paa_prof_enable(0)
-        rows = [(v, out[3 * v], out[3 * v + 1], out[3 * v + 2]) for v in range(16) if out[3 * v] > 0]
+        rows = [(v, out[3 * v], out[3 * v + 1], out[3 * v + 2]) for v in range(32) if out[3 * v] > 0]
         rows.sort(key=lambda r: -r[2])
         if rows:
             v, n, ms, fl = rows[0]

@@ -30,42 +30,62 @@ struct GemmArgs {
 };
 
 // ---- epilogue shared by both main loops ---------------------------------------------------------
-template <int BN>
-__device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[2][BN / 64], int m0, int n0, int z1, int z2,
+// Lane (lr, lh) of a wave holds column n = ... + lr and rows (e&3) + 8(e>>2) + 4 lh of each 32 x 32 accumulator.
+// All per-element offsets are 32-bit and relative to per-wave base pointers (tile-local row * ld + column).
+template <int BN, int MI = 2>
+__device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[MI][BN / 64], int m0, int n0, int z1, int z2,
                                          int wm, int wn, int lr, int lh) {
     constexpr int NJ = BN / 64;
-    const int64_t coff = z1 * d.c_s1 + z2 * d.c_s2;
-    float* C = d.C ? d.C + coff : nullptr;
-    float* Cp = d.C_pre ? d.C_pre + coff : nullptr;
-    unsigned short* Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + coff : nullptr;
-    unsigned short* Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + coff : nullptr;
-    const float* aux = d.aux ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2 : nullptr;
-    const float* res = d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr;
-    const float* bias = d.bias ? d.bias + z2 * d.bias_s2 : nullptr;
+    const int mw = m0 + wm * (32 * MI) + 4 * lh;           // first row this lane owns
+    const int nw = n0 + wn * (BN / 2) + lr;                // first column this lane owns
+    const int64_t coff = z1 * d.c_s1 + z2 * d.c_s2 + (int64_t)mw * d.ldc + nw;
+    float* __restrict__ C = d.C ? d.C + coff : nullptr;
+    float* __restrict__ Cp = d.C_pre ? d.C_pre + coff : nullptr;
+    unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + coff : nullptr;
+    unsigned short* __restrict__ Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + coff : nullptr;
+    const float* __restrict__ aux = d.aux ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2 + (int64_t)mw * d.ld_aux + nw : nullptr;
+    const float* __restrict__ res = d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 + (int64_t)mw * d.ld_res + nw : nullptr;
+    const float* __restrict__ bias = d.bias ? d.bias + z2 * d.bias_s2 + nw : nullptr;
+    const int ldc = (int)d.ldc, ld_aux = (int)d.ld_aux, ld_res = (int)d.ld_res;
+    const int period = d.row_period;
+    const int mrem0 = period > 0 ? mw % period : 0;
+    const int act = d.act;
+    const float alpha = d.alpha;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + lr;
-        if (n >= d.N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const int dn = j * 32;
+        if (nw + dn >= d.N) continue;
+        const float bv = bias ? bias[dn] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
+            float ax[16];
+            if (act == PAA_ACT_GELU_GRAD) {          // issue the aux loads of this accumulator together
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
+                    ax[e] = (mw + dm < d.M) ? aux[dm * ld_aux + dn] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m >= d.M) continue;
-                float v = acc[i][j][e] * d.alpha + bv;
-                const int64_t ci = (int64_t)m * d.ldc + n;
-                if (d.act == PAA_ACT_GELU) {
-                    if (Cp) Cp[ci] = v;
+                const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
+                if (mw + dm >= d.M) continue;
+                float v = acc[i][j][e] * alpha + bv;
+                const int ci = dm * ldc + dn;
+                bool dead = false;
+                if (period > 0) {
+                    int rem = mrem0 + dm;
+                    if (rem >= period) rem = (period >= 32 * MI * 2) ? rem - period : rem % period;
+                    dead = rem >= d.row_valid;
+                }
+                if (act == PAA_ACT_GELU) {
+                    if (Cp) Cp[ci] = dead ? 0.f : v;
                     v = gelu_f(v);
-                } else if (d.act == PAA_ACT_GELU_GRAD) {
-                    v *= gelu_grad_f(aux[(int64_t)m * d.ld_aux + n]);
+                } else if (act == PAA_ACT_GELU_GRAD) {
+                    v *= gelu_grad_f(ax[e]);
                 }
-                if (res) v += res[(int64_t)m * d.ld_res + n];
-                if (d.row_period > 0 && (m % d.row_period) >= d.row_valid) {
-                    v = 0.f;
-                    if (Cp) Cp[ci] = 0.f;
-                }
+                if (res) v += res[dm * ld_res + dn];
+                if (dead) v = 0.f;
                 if (C) {
                     if (d.accumulate) v += C[ci];
                     C[ci] = v;
@@ -270,9 +290,9 @@ __global__ __launch_bounds__(G_NT) void k_gemm(GemmArgs g) {
 // ds_read_b128 lane groups hit 16 distinct 16-byte slots).  16 (BN=128) MFMAs per wave per K tile.
 constexpr int H_BK = 64, H_LD = 72;
 
-template <int ROWS, bool IS_A>
+template <int ROWS, bool IS_A, int NT>
 __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned short* __restrict__ base, int64_t ld,
-                                        int r0, int k0, int rlim, uint4 (&v)[ROWS / 32]) {
+                                        int r0, int k0, int rlim, uint4 (&v)[ROWS * 8 / NT]) {
     const int tid = threadIdx.x;
     const int k = k0 + ((tid & 7) << 3);
     int64_t koff = k;
@@ -283,8 +303,8 @@ __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned s
         koff = (int64_t)js * d.a_kseg_stride + kc;
     }
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int r = r0 + (tid >> 3) + 32 * i;
+    for (int i = 0; i < ROWS * 8 / NT; ++i) {
+        const int r = r0 + (tid >> 3) + (NT / 8) * i;
         uint4 x = make_uint4(0u, 0u, 0u, 0u);
         bool ok = (r < rlim) && (k < d.K);
         const unsigned short* p;
@@ -300,22 +320,25 @@ __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned s
     }
 }
 
-template <int ROWS>
-__device__ __forceinline__ void store_bf(unsigned short* lds, const uint4 (&v)[ROWS / 32]) {
+template <int ROWS, int NT>
+__device__ __forceinline__ void store_bf(unsigned short* lds, const uint4 (&v)[ROWS * 8 / NT]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i)
-        *reinterpret_cast<uint4*>(lds + ((tid >> 3) + 32 * i) * H_LD + ((tid & 7) << 3)) = v[i];
+    for (int i = 0; i < ROWS * 8 / NT; ++i)
+        *reinterpret_cast<uint4*>(lds + ((tid >> 3) + (NT / 8) * i) * H_LD + ((tid & 7) << 3)) = v[i];
 }
 
-template <int BN, int PREC>
-__global__ __launch_bounds__(G_NT) void k_gemm_bf(GemmArgs g) {
+// WM x 2 waves; each wave owns a (BM / WM) x (BN / 2) sub-tile = MI x NJ accumulators of 32 x 32.
+template <int BM, int BN, int PREC, int WM>
+__global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_gemm_bf(GemmArgs g) {
+    constexpr int NT = WM * 128;
     constexpr int NPL = PREC ? 2 : 1;
     constexpr int NJ = BN / 64;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[NPL * (G_BM + BN) * H_LD];
+    constexpr int MI = BM / (32 * WM);
+    __shared__ __attribute__((aligned(16))) unsigned short smem[NPL * (BM + BN) * H_LD];
     unsigned short* sAh = smem;
-    unsigned short* sAl = smem + (PREC ? G_BM * H_LD : 0);
-    unsigned short* sBh = smem + NPL * G_BM * H_LD;
+    unsigned short* sAl = smem + (PREC ? BM * H_LD : 0);
+    unsigned short* sBh = smem + NPL * BM * H_LD;
     unsigned short* sBl = sBh + (PREC ? BN * H_LD : 0);
 
     const paa_gemm_desc& d = g.d;
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(G_NT) void k_gemm_bf(GemmArgs g) {
     const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
     const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-    const int m0 = tm * G_BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.y;
     const int z1 = z / d.batch2, z2 = z - z1 * d.batch2;
     const int64_t aoff = z1 * d.a_s1 + z2 * d.a_s2, boff = z1 * d.b_s1 + z2 * d.b_s2;
@@ -337,42 +360,42 @@ __global__ __launch_bounds__(G_NT) void k_gemm_bf(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
 
-    f32x16 acc[2][NJ];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    uint4 rah[G_BM / 32], rbh[BN / 32], ral[PREC ? G_BM / 32 : 1], rbl[PREC ? BN / 32 : 1];
+    uint4 rah[BM * 8 / NT], rbh[BN * 8 / NT], ral[PREC ? BM * 8 / NT : 1], rbl[PREC ? BN * 8 / NT : 1];
     const int nk = (d.K + H_BK - 1) / H_BK;
-    load_bf<G_BM, true>(d, Ah, d.lda, m0, 0, d.M, rah);
-    load_bf<BN, false>(d, Bh, d.ldb, n0, 0, d.N, rbh);
+    load_bf<BM, true, NT>(d, Ah, d.lda, m0, 0, d.M, rah);
+    load_bf<BN, false, NT>(d, Bh, d.ldb, n0, 0, d.N, rbh);
     if constexpr (PREC) {
-        load_bf<G_BM, true>(d, Al, d.lda, m0, 0, d.M, ral);
-        load_bf<BN, false>(d, Bl, d.ldb, n0, 0, d.N, rbl);
+        load_bf<BM, true, NT>(d, Al, d.lda, m0, 0, d.M, ral);
+        load_bf<BN, false, NT>(d, Bl, d.ldb, n0, 0, d.N, rbl);
     }
     for (int kt = 0; kt < nk; ++kt) {
-        store_bf<G_BM>(sAh, rah);
-        store_bf<BN>(sBh, rbh);
-        if constexpr (PREC) { store_bf<G_BM>(sAl, ral); store_bf<BN>(sBl, rbl); }
+        store_bf<BM, NT>(sAh, rah);
+        store_bf<BN, NT>(sBh, rbh);
+        if constexpr (PREC) { store_bf<BM, NT>(sAl, ral); store_bf<BN, NT>(sBl, rbl); }
         __syncthreads();
         if (kt + 1 < nk) {
             const int k0 = (kt + 1) * H_BK;
-            load_bf<G_BM, true>(d, Ah, d.lda, m0, k0, d.M, rah);
-            load_bf<BN, false>(d, Bh, d.ldb, n0, k0, d.N, rbh);
+            load_bf<BM, true, NT>(d, Ah, d.lda, m0, k0, d.M, rah);
+            load_bf<BN, false, NT>(d, Bh, d.ldb, n0, k0, d.N, rbh);
             if constexpr (PREC) {
-                load_bf<G_BM, true>(d, Al, d.lda, m0, k0, d.M, ral);
-                load_bf<BN, false>(d, Bl, d.ldb, n0, k0, d.N, rbl);
+                load_bf<BM, true, NT>(d, Al, d.lda, m0, k0, d.M, ral);
+                load_bf<BN, false, NT>(d, Bl, d.ldb, n0, k0, d.N, rbl);
             }
         }
 #pragma unroll
         for (int ks = 0; ks < H_BK / 16; ++ks) {
-            bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+            bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = (wm * 64 + i * 32 + lr) * H_LD + ks * 16 + lh * 8;
+            for (int i = 0; i < MI; ++i) {
+                const int off = (wm * (32 * MI) + i * 32 + lr) * H_LD + ks * 16 + lh * 8;
                 ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
                 if (PREC) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
             }
@@ -383,7 +406,7 @@ __global__ __launch_bounds__(G_NT) void k_gemm_bf(GemmArgs g) {
                 if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sBl + off);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     if (PREC) {
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(G_NT) void k_gemm_bf(GemmArgs g) {
         }
         __syncthreads();
     }
-    epilogue<BN>(d, acc, m0, n0, z1, z2, wm, wn, lr, lh);
+    epilogue<BN, MI>(d, acc, m0, n0, z1, z2, wm, wn, lr, lh);
 }
 
 template <int BN, int PREC>
@@ -438,7 +461,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     g.d = d;
     const bool narrow = d.N <= 64;
     const int bn = narrow ? 64 : 128;
-    g.tiles_m = cdiv(d.M, G_BM);
+    const bool tall = d.operand_bf16 && !narrow && d.M >= 2048;     // 256 x 128 tile, 8 waves     // 256 x 128 tile: higher FLOP per LDS/L2 byte
+    g.tiles_m = cdiv(d.M, tall ? 256 : G_BM);
     g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
@@ -448,8 +472,9 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         g_prof.variant[g_prof.n] = (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     }
     if (d.operand_bf16) {
-        if (narrow) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<64, 1>), grid, dim3(G_NT), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<64, 0>), grid, dim3(G_NT), 0, st, g); }
-        else { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 1>), grid, dim3(G_NT), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 0>), grid, dim3(G_NT), 0, st, g); }
+        if (narrow) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 64, 1, 2>), grid, dim3(256), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 64, 0, 2>), grid, dim3(256), 0, st, g); }
+        else if (tall) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<256, 128, 1, 4>), grid, dim3(512), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<256, 128, 0, 4>), grid, dim3(512), 0, st, g); }
+        else { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 128, 1, 2>), grid, dim3(256), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 128, 0, 2>), grid, dim3(256), 0, st, g); }
     } else if (narrow) { if (d.precision) launch_gemm<64, 1>(g, grid, st); else launch_gemm<64, 0>(g, grid, st); }
     else { if (d.precision) launch_gemm<128, 1>(g, grid, st); else launch_gemm<128, 0>(g, grid, st); }
     if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }

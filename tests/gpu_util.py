@@ -24,7 +24,8 @@ def run_gemm(d: dict, bufs: dict, offs: dict = None):
     for k, v in d.items():
         if k in ("A", "B", "C", "bias", "aux", "residual", "C_pre", "A_lo", "B_lo", "Cb", "Cb_lo"):
             t = bufs[v]
-            setattr(desc, k, t.data_ptr() + t.element_size() * offs.get(k, offs.get(k[0], 0) if k.endswith('_lo') else 0))
+            base = {'A_lo': 'A', 'B_lo': 'B', 'Cb': 'C', 'Cb_lo': 'C', 'C_pre': 'C'}.get(k, k)
+            setattr(desc, k, t.data_ptr() + t.element_size() * offs.get(k, offs.get(base, 0)))
         else:
             setattr(desc, k, v)
     _lib.check(_lib.lib().paa_gemm(C.byref(desc), _lib.stream_ptr()))
