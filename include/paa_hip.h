@@ -145,6 +145,10 @@ paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
  * (bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig) and resets the counters. */
 paa_status paa_prof_enable(int max_launches);
 paa_status paa_prof_read(double* out96);
+/* Fused attention (head_dim 64, bf16 planes as uint16): qkv (B*P, 3H) = Q|K|V, ctx/dctx (B*P, H), lse/delta (B*nh, Tp) */
+paa_status paa_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int P, int Tp, int H, int nh, void* stream);
+paa_status paa_attn_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, float* delta, void* dqkv,
+                        int B, int T, int P, int Tp, int H, int nh, void* stream);
 paa_status paa_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats,
                              int rows, int cols, float eps, void* stream);
 paa_status paa_layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, float* dx,

@@ -1,0 +1,313 @@
+// Fused (flash-style) multi-head self-attention for gfx950, head_dim 64, bf16 operands, no mask
+// (the reference passes no attention_mask: core/loss_helpers.py:21; HF modeling_wav2vec2.py:466-548).
+//
+//   forward :  O = softmax(Q K^T * scale) V, plus the per-row log-sum-exp (base 2) for the backward
+//   backward:  dQ, dK, dV from dO, recomputing P = exp2(S*c - lse) tile by tile; no T x T matrix in HBM.
+//
+// Mapping (all three kernels share it).  A workgroup is 4 waves; a wave owns 32 "own" positions that sit on
+// the 32 MFMA columns (lane & 31), and sweeps the "other" positions in tiles of 32 that sit on the
+// accumulator rows: with v_mfma_f32_32x32x16_bf16 the score tile X[other][own] has its rows in the 16
+// accumulator registers (row = (e&3) + 8(e>>2) + 4(lane>>5)) and its columns on the lanes.  Products that
+// then sum over `other` take bf16(X) straight from the accumulator registers as their B operand (k order
+// inside a 16-deep step: 16s + 8(j>>2) + 4h + (j&3), so the A operand is read from a TRANSPOSED LDS image
+// [d][other] with two 8-byte reads per step).  Every statistic of an own position (running max / sum, lse,
+// delta) lives in its two lanes (lane, lane^32): no LDS reductions.
+//   forward, dQ : own = queries, other = keys          dK/dV : own = keys, other = queries
+// Q/K/V/dO are rows of the (M, 3H) / (M, H) bf16 planes the GEMM epilogues write; outputs go back as bf16.
+#include "model_kernels.h"
+
+namespace paa {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AT_D = 64;            // head dim
+constexpr int AT_RM = 72;           // row-major tile row stride (bf16): 144 B, conflict-free ds_read_b128
+constexpr int AT_TR = 36;           // transposed tile row stride (bf16): 72 B, conflict-free ds_read_b64
+
+// stage a 32 x 64 tile (rows r0.., valid while < rlim) of a bf16 matrix with row stride ld:
+//   rm: row-major [32][AT_RM] (optional)    tr: transposed [64][AT_TR] (optional)
+__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ src, int64_t ld, int r0, int rlim,
+                                           unsigned short* rm, unsigned short* tr) {
+    const int tid = threadIdx.x;
+    const int row = tid >> 3, ch = tid & 7;
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (r0 + row < rlim) x = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + row) * ld + ch * 8);
+    if (rm) *reinterpret_cast<uint4*>(rm + row * AT_RM + ch * 8) = x;
+    if (tr) {
+        const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tr[(ch * 8 + 2 * j) * AT_TR + row] = (unsigned short)(w[j] & 0xffffu);
+            tr[(ch * 8 + 2 * j + 1) * AT_TR + row] = (unsigned short)(w[j] >> 16);
+        }
+    }
+}
+
+// A fragment of k-step s from a row-major tile: lane (lr, lh) -> row lr, elements 16s + 8lh .. +7
+__device__ __forceinline__ bf16x8 frag_rm(const unsigned short* rm, int lr, int lh, int s) {
+    return *reinterpret_cast<const bf16x8*>(rm + lr * AT_RM + 16 * s + 8 * lh);
+}
+// A fragment of k-step s2 from a transposed tile, in the accumulator's k order: row (dt*32 + lr),
+// elements j<4: 16 s2 + 4 lh + j ; j>=4: 16 s2 + 8 + 4 lh + (j-4)
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned short* tr, int lr, int lh, int dt, int s2) {
+    const unsigned short* p = tr + (dt * 32 + lr) * AT_TR + 16 * s2 + 4 * lh;
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 8);
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+// bf16 pack of accumulator registers 8 s2 .. 8 s2 + 7 (the B operand of the follow-up product)
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[16], int s2) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)bf16_bits(v[8 * s2 + j]);
+    return r;
+}
+// own-position operand fragments (B operand of X = other x own): 16 B at row `own`, k = 16s + 8lh
+__device__ __forceinline__ void load_own(const unsigned short* __restrict__ src, int64_t ld, int row, int lh, bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + 16 * s + 8 * lh);
+}
+// write the transposed accumulators acc[dt][e] (d = dt*32 + (e&3) + 8(e>>2) + 4lh, own = lr) as bf16 rows
+__device__ __forceinline__ void store_own(unsigned short* __restrict__ dst, int64_t ld, int row, int lh,
+                                          const f32x16 (&acc)[2], float mul) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = dt * 32 + 8 * g4 + 4 * lh;
+            const unsigned a = bf16_bits(acc[dt][4 * g4] * mul) | ((unsigned)bf16_bits(acc[dt][4 * g4 + 1] * mul) << 16);
+            const unsigned b = bf16_bits(acc[dt][4 * g4 + 2] * mul) | ((unsigned)bf16_bits(acc[dt][4 * g4 + 3] * mul) << 16);
+            *reinterpret_cast<uint2*>(dst + (int64_t)row * ld + d) = make_uint2(a, b);
+        }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sK[32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sVt[64 * AT_TR];
+    const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    const int qc = q < a.T ? q : a.T - 1;
+    const int64_t ld = 3 * (int64_t)a.H;
+    const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
+    bf16x8 qf[4];
+    load_own(base, ld, qc, lh, qf);
+    const float c = a.scale * 1.44269504088896341f;
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
+    const int nt = (a.T + 31) / 32;
+    for (int kt = 0; kt < nt; ++kt) {
+        stage_tile(base + a.H, ld, kt * 32, a.T, sK, nullptr);
+        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, nullptr, sVt);
+        __syncthreads();
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sK, lr, lh, ks), qf[ks], s, 0, 0, 0);
+        float p[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            p[e] = key < a.T ? s[e] * c : -INFINITY;
+            mx = fmaxf(mx, p[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { p[e] = exp2f(p[e] - mn); rs += p[e]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(p, s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sVt, lr, lh, dt, s2), pb, o[dt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (q < a.T) {
+        store_own(a.ctx + (int64_t)b * a.P * a.H + h * AT_D, a.H, q, lh, o, 1.f / l);
+        if (lh == 0) a.lse[(int64_t)bh * a.Tp + q] = m + log2f(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------- backward: dQ
+// own = queries.  Also computes delta = rowsum(dO * O) and stores it for the dK/dV kernel.
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sK[32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sKt[64 * AT_TR];
+    __shared__ __attribute__((aligned(16))) unsigned short sV[32 * AT_RM];
+    const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    const int qc = q < a.T ? q : a.T - 1;
+    const int64_t ld = 3 * (int64_t)a.H;
+    const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
+    const unsigned short* dob = a.dctx + (int64_t)b * a.P * a.H + h * AT_D;
+    const unsigned short* ob = a.ctx + (int64_t)b * a.P * a.H + h * AT_D;
+    bf16x8 qf[4], dof[4], of[4];
+    load_own(base, ld, qc, lh, qf);
+    load_own(dob, a.H, qc, lh, dof);
+    load_own(ob, a.H, qc, lh, of);
+    float delta = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf16_to_f32((unsigned short)dof[s][j]) * bf16_to_f32((unsigned short)of[s][j]);
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = a.lse[(int64_t)bh * a.Tp + qc];
+    if (q < a.T && lh == 0) a.delta[(int64_t)bh * a.Tp + q] = delta;
+    const float c = a.scale * 1.44269504088896341f;
+    f32x16 dq[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+    const int nt = (a.T + 31) / 32;
+    for (int kt = 0; kt < nt; ++kt) {
+        stage_tile(base + a.H, ld, kt * 32, a.T, sK, sKt);
+        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, sV, nullptr);
+        __syncthreads();
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sK, lr, lh, ks), qf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sV, lr, lh, ks), dof[ks], dp, 0, 0, 0);
+        }
+        float ds[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float p = key < a.T ? exp2f(s[e] * c - lse) : 0.f;
+            ds[e] = p * (dp[e] - delta) * a.scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 db = pack8(ds, s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sKt, lr, lh, dt, s2), db, dq[dt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (q < a.T) store_own(a.dqkv + (int64_t)b * a.P * ld + h * AT_D, ld, q, lh, dq, 1.f);
+}
+
+// ---------------------------------------------------------------------------------- backward: dK, dV
+// own = keys (lanes), other = queries (accumulator rows).
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sQ[32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sQt[64 * AT_TR];
+    __shared__ __attribute__((aligned(16))) unsigned short sdO[32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sdOt[64 * AT_TR];
+    __shared__ float sLse[32], sDel[32];
+    const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const int key = blockIdx.x * 128 + wave * 32 + lr;
+    const int kc = key < a.T ? key : a.T - 1;
+    const int64_t ld = 3 * (int64_t)a.H;
+    const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
+    const unsigned short* dob = a.dctx + (int64_t)b * a.P * a.H + h * AT_D;
+    bf16x8 kf[4], vf[4];
+    load_own(base + a.H, ld, kc, lh, kf);
+    load_own(base + 2 * a.H, ld, kc, lh, vf);
+    const float c = a.scale * 1.44269504088896341f;
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[0][e] = 0.f; dk[1][e] = 0.f; dv[0][e] = 0.f; dv[1][e] = 0.f; }
+    const int nt = (a.T + 31) / 32;
+    for (int qt = 0; qt < nt; ++qt) {
+        stage_tile(base, ld, qt * 32, a.T, sQ, sQt);
+        stage_tile(dob, a.H, qt * 32, a.T, sdO, sdOt);
+        if (threadIdx.x < 32) {
+            const int qq = qt * 32 + threadIdx.x;
+            sLse[threadIdx.x] = qq < a.T ? a.lse[(int64_t)bh * a.Tp + qq] : INFINITY;     // exp2(-inf) = 0 for pad queries
+            sDel[threadIdx.x] = qq < a.T ? a.delta[(int64_t)bh * a.Tp + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sQ, lr, lh, ks), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sdO, lr, lh, ks), vf[ks], dp, 0, 0, 0);
+        }
+        float p[16], ds[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            p[e] = exp2f(s[e] * c - sLse[r]);
+            ds[e] = p[e] * (dp[e] - sDel[r]) * a.scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(p, s2), db = pack8(ds, s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sdOt, lr, lh, dt, s2), pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sQt, lr, lh, dt, s2), db, dk[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (key < a.T) {
+        unsigned short* o = a.dqkv + (int64_t)b * a.P * ld + h * AT_D;
+        store_own(o + a.H, ld, key, lh, dk, 1.f);
+        store_own(o + 2 * a.H, ld, key, lh, dv, 1.f);
+    }
+}
+
+static paa_status attn_check(const AttnArgs& a, int B, int head_dim) {
+    if (head_dim != AT_D) PAA_FAIL(PAA_ERR_ARG, "fused attention supports head_dim 64 only (got %d)", head_dim);
+    if (a.T < 1 || B < 1 || (a.H & 7)) PAA_FAIL(PAA_ERR_ARG, "fused attention: bad shape");
+    return PAA_OK;
+}
+
+paa_status attn_fwd(const AttnArgs& a, int B, int head_dim, hipStream_t st) {
+    PAA_TRY(attn_check(a, B, head_dim));
+    hipLaunchKernelGGL(k_attn_fwd, dim3(cdiv(a.T, 128), B * a.nh), dim3(256), 0, st, a);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+paa_status attn_bwd(const AttnArgs& a, int B, int head_dim, hipStream_t st) {
+    PAA_TRY(attn_check(a, B, head_dim));
+    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(cdiv(a.T, 128), B * a.nh), dim3(256), 0, st, a);
+    PAA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(cdiv(a.T, 128), B * a.nh), dim3(256), 0, st, a);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+}  // namespace paa
+
+// Test entries: bf16 planes as uint16; qkv (B*P, 3H), ctx / dctx (B*P, H), lse / delta (B*nh, Tp) f32.
+extern "C" paa_status paa_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int P, int Tp, int H, int nh,
+                                   void* stream) {
+    paa::AttnArgs a{};
+    a.qkv = (const unsigned short*)qkv; a.ctx = (unsigned short*)ctx; a.lse = lse;
+    a.T = T; a.P = P; a.Tp = Tp; a.H = H; a.nh = nh; a.scale = 1.0f / sqrtf((float)(H / nh));
+    return paa::attn_fwd(a, B, H / nh, (hipStream_t)stream);
+}
+extern "C" paa_status paa_attn_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, float* delta,
+                                   void* dqkv, int B, int T, int P, int Tp, int H, int nh, void* stream) {
+    paa::AttnArgs a{};
+    a.qkv = (const unsigned short*)qkv; a.ctx = (unsigned short*)ctx; a.lse = (float*)lse;
+    a.dctx = (const unsigned short*)dctx; a.delta = delta; a.dqkv = (unsigned short*)dqkv;
+    a.T = T; a.P = P; a.Tp = Tp; a.H = H; a.nh = nh; a.scale = 1.0f / sqrtf((float)(H / nh));
+    return paa::attn_bwd(a, B, H / nh, (hipStream_t)stream);
+}

@@ -51,7 +51,9 @@ struct ConvL {
 struct EncL {
     CBf wqkv, wqkv_t, wo, wo_t, w1, w1_t, w2, w2_t;
     const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b;
-    float *qkv, *P, *ln1_in, *st1, *fpre, *ln2_in, *st2;
+    float *qkv = nullptr, *P = nullptr, *ln1_in, *st1, *fpre, *ln2_in, *st2;   // qkv, P: materialised attention only
+    Bf qkvH{nullptr, nullptr}, ctxH{nullptr, nullptr};                          // fused attention: bf16 Q|K|V and O
+    float* lse = nullptr;
 };
 
 __global__ void k_copy_logits(const float* __restrict__ src, float* __restrict__ dst, int B, int T, int P, int V) {
@@ -80,6 +82,7 @@ struct paa_model {
     paa_arch a;
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
+    bool fused;                      // flash-style attention kernels (bf16 mode, head_dim 64); else materialised scores
     std::vector<ConvL> conv;
     std::vector<EncL> enc;
     std::map<std::string, std::pair<const float*, int64_t>> tensors;
@@ -97,7 +100,8 @@ struct paa_model {
     float *fp_stats, *h0, *pos_pre, *hsum, *enc_stats, *xa, *xb, *final_in;
     float *logits, *dlogits, *nll, *ctc_work;
     Bf dlogitsH, dxaH, dxbH, dqkvH, dfpreH, dposH, dh0H;
-    float *dxa, *dxb, *dctx, *dP, *dh0, *dfn;
+    float *dxa, *dxb, *dctx = nullptr, *dP = nullptr, *dh0, *dfn, *delta = nullptr;
+    Bf dctxH{nullptr, nullptr};
     int S_cap;
 };
 
@@ -137,6 +141,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     if (max_batch < 1 || length < 1) PAA_FAIL(PAA_ERR_SIZE, "max_batch/length");
     paa_model* m = new paa_model();
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
+    m->fused = (m->prec == 0) && (a.hidden / a.heads == 64);
     for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
 
     // ---- shapes: conv output lengths and the padded row counts (P_{i-1} = s_i * P_i) ----
@@ -247,9 +252,12 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         m->xa = take(MH); m->xaH = take_bf(MH); m->xb = take(MH); m->xbH = take_bf(MH);
         m->ctxH = take_bf(MH); m->factH = take_bf(MF); m->xfinalH = take_bf(MH); m->final_in = take(MH);
         const int64_t PM = (int64_t)B * nh * m->Tp * m->Tp;
+        const int64_t LS = (int64_t)B * nh * m->Tp;
         for (int l = 0; l < a.layers; ++l) {
             EncL& e = m->enc[l];
-            e.qkv = take(3 * MH); e.P = take(PM); e.ln1_in = take(MH); e.st1 = take((int64_t)m->M * 2);
+            if (m->fused) { e.qkvH = take_bf(3 * MH); e.ctxH = take_bf(MH); e.lse = take(LS); }
+            else { e.qkv = take(3 * MH); e.P = take(PM); }
+            e.ln1_in = take(MH); e.st1 = take((int64_t)m->M * 2);
             e.fpre = take(MF); e.ln2_in = take(MH); e.st2 = take((int64_t)m->M * 2);
         }
         m->logits = take((int64_t)m->M * V); m->dlogits = take((int64_t)m->M * V); m->dlogitsH = take_bf((int64_t)m->M * V);
@@ -257,7 +265,9 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         m->S_cap = std::max(1, std::min(4000, m->T));     // labels longer than T_e are infeasible anyway
         m->ctc_work = take((int64_t)B * ctc_work_floats_per_clip(m->T, V, m->S_cap));
         m->dxa = take(MH); m->dxaH = take_bf(MH); m->dxb = take(MH); m->dxbH = take_bf(MH);
-        m->dqkvH = take_bf(3 * MH); m->dctx = take(MH); m->dP = take(PM);
+        m->dqkvH = take_bf(3 * MH);
+        if (m->fused) { m->dctxH = take_bf(MH); m->delta = take(LS); }
+        else { m->dctx = take(MH); m->dP = take(PM); }
         m->dfpreH = take_bf(MF); m->dposH = take_bf(MH); m->dh0 = take(MH); m->dh0H = take_bf(MH); m->dfn = take(MC);
         if (!pass) {
             m->arena_floats = off;
@@ -370,6 +380,15 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             PAA_TRY(layernorm_fwd(x, e.ln1_g, e.ln1_b, nullptr, e.st1, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));
             attn_in = ro(m->xbH);
         }
+        CBf ctxH = ro(m->ctxH);
+        if (m->fused) {
+            PAA_TRY(linear(m, attn_in, e.wqkv, e.bqkv, nullptr, e.qkvH, M, 3 * H, H, st));
+            AttnArgs aa{};
+            aa.qkv = e.qkvH.hi; aa.ctx = e.ctxH.hi; aa.lse = e.lse;
+            aa.T = T; aa.P = P; aa.Tp = Tp; aa.H = H; aa.nh = nh; aa.scale = scale;
+            PAA_TRY(attn_fwd(aa, B, hd, st));
+            ctxH = ro(e.ctxH);
+        } else {
         PAA_TRY(linear(m, attn_in, e.wqkv, e.bqkv, e.qkv, NOBF, M, 3 * H, H, st));
         {   // S = Q K^T  per (clip, head)
             paa_gemm_desc d = gd(m, e.qkv, e.qkv + H, e.P, T, T, hd, 3 * H, 3 * H, Tp);
@@ -387,8 +406,9 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             d.c_s1 = (int64_t)P * H; d.c_s2 = hd;
             PAA_TRY(gemm(d, st));
         }
+        }
         if (!a.stable_ln) {
-            PAA_TRY(linear(m, ro(m->ctxH), e.wo, e.bo, e.ln1_in, NOBF, M, H, H, st, x));                        // r1 = x + attn
+            PAA_TRY(linear(m, ctxH, e.wo, e.bo, e.ln1_in, NOBF, M, H, H, st, x));                                // r1 = x + attn
             PAA_TRY(layernorm_fwd(e.ln1_in, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));   // y1
             PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
             PAA_TRY(linear(m, ro(m->factH), e.w2, e.b2, e.ln2_in, NOBF, M, H, F, st, m->xb));                   // r2 = y1 + ffn
@@ -396,7 +416,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             else PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, m->xa, e.st2, M, H, a.ln_eps, m->xaH, NOBF, nullptr, st));
             x = m->xa; xH = ro(m->xaH);
         } else {
-            PAA_TRY(linear(m, ro(m->ctxH), e.wo, e.bo, e.ln2_in, NOBF, M, H, H, st, x));                        // r1 = x + attn
+            PAA_TRY(linear(m, ctxH, e.wo, e.bo, e.ln2_in, NOBF, M, H, H, st, x));                                // r1 = x + attn
             PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, nullptr, e.st2, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));
             PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
             float* xo = lastl ? m->final_in : m->enc[l + 1].ln1_in;
@@ -432,6 +452,13 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             PAA_TRY(linear(m, ro(m->dfpreH), e.w1_t, nullptr, dx2, NOBF, M, H, F, st));                                   // dn2
             PAA_TRY(layernorm_bwd(dx2, e.ln2_in, e.ln2_g, e.st2, dx, nullptr, dx2, dx2H, M, H, st));                     // dr1 = dr2 + LN2'
         }
+        if (m->fused) {
+            PAA_TRY(linear(m, ro(dx2H), e.wo_t, nullptr, nullptr, m->dctxH, M, H, H, st));
+            AttnArgs aa{};
+            aa.qkv = e.qkvH.hi; aa.ctx = e.ctxH.hi; aa.lse = e.lse; aa.dctx = m->dctxH.hi; aa.delta = m->delta; aa.dqkv = m->dqkvH.hi;
+            aa.T = T; aa.P = P; aa.Tp = Tp; aa.H = H; aa.nh = nh; aa.scale = scale;
+            PAA_TRY(attn_bwd(aa, B, hd, st));
+        } else {
         PAA_TRY(linear(m, ro(dx2H), e.wo_t, nullptr, m->dctx, NOBF, M, H, H, st));
         const int64_t sq = (int64_t)P * 3 * H, sp = (int64_t)nh * Tp * Tp, sp2 = (int64_t)Tp * Tp, sc = (int64_t)P * H;
         {   // dP = dctx V^T
@@ -463,6 +490,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             d.batch = B * nh; d.batch2 = nh;
             d.a_s1 = sp; d.a_s2 = sp2; d.b_s1 = sq; d.b_s2 = hd; d.c_s1 = sq; d.c_s2 = hd;
             PAA_TRY(gemm(d, st));
+        }
         }
         if (!a.stable_ln) {
             PAA_TRY(linear(m, ro(m->dqkvH), e.wqkv_t, nullptr, dx, NOBF, M, H, 3 * H, st, dx2));          // dx = dr1 + dqkv Wqkv
@@ -589,8 +617,8 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
     for (int l = 0; l < a.layers && !p && !pb.hi; ++l) {
         const EncL& e = m->enc[l];
         const std::string b = "L" + std::to_string(l);
-        if (n == b + ".qkv") { p = e.qkv; cnt = M * 3 * H; }
-        else if (n == b + ".P") { p = e.P; cnt = (int64_t)B * a.heads * m->Tp * m->Tp; }
+        if (n == b + ".qkv") { if (e.qkv) p = e.qkv; else pb = e.qkvH; cnt = M * 3 * H; }
+        else if (n == b + ".P" && e.P) { p = e.P; cnt = (int64_t)B * a.heads * m->Tp * m->Tp; }
         else if (n == b + ".ln1_in") { p = e.ln1_in; cnt = M * H; }
         else if (n == b + ".fpre") { p = e.fpre; cnt = M * F; }
         else if (n == b + ".ln2_in") { p = e.ln2_in; cnt = M * H; }

@@ -51,4 +51,18 @@ paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpa
                float grad_scale, float* nll, float* dlogits, Bf dlb, float* work, hipStream_t st);
 paa_status sum_small(const float* x, int n, float* out, hipStream_t st);
 
+// Fused attention (attention.hip): bf16 hi planes only (bf16 mode), head_dim 64.
+struct AttnArgs {
+    const unsigned short* qkv;      // (M, 3H): Q | K | V
+    unsigned short* ctx;            // (M, H)   forward output O            (read by the backward for delta)
+    float* lse;                     // (B*nh, Tp) log2-domain log-sum-exp
+    const unsigned short* dctx;     // (M, H)   dO
+    float* delta;                   // (B*nh, Tp) rowsum(dO * O)
+    unsigned short* dqkv;           // (M, 3H): dQ | dK | dV
+    int T, P, Tp, H, nh;
+    float scale;                    // head_dim^-0.5
+};
+paa_status attn_fwd(const AttnArgs& a, int B, int head_dim, hipStream_t st);
+paa_status attn_bwd(const AttnArgs& a, int B, int head_dim, hipStream_t st);
+
 }  // namespace paa

@@ -241,3 +241,40 @@ def test_ctc(T, S_max, lens):
     e2 = rel_err(dl.cpu()[fin], lr.grad[fin])
     print(f"ctc T={T}: nll {e1:.2e} grad {e2:.2e}")
     assert e1 < 2e-6 and e2 < 2e-6
+
+
+@pytest.mark.parametrize("T,B,nh", [(499, 2, 3), (70, 1, 2), (32, 1, 1), (131, 2, 2)])
+def test_fused_attention(T, B, nh):
+    """Flash-style attention forward / backward (bf16 operands) vs torch float64 on the same bf16-rounded inputs."""
+    from paa_amd.model import bf16_bits, bf16_to_f32
+    torch.manual_seed(3)
+    hd, P, Tp = 64, T + 1, (T + 31) // 32 * 32
+    H = nh * hd
+    qkv = (torch.randn(B, P, 3 * H) * 1.5).numpy()
+    do = torch.randn(B, P, H).numpy()
+    qb, dob = bf16_bits(qkv), bf16_bits(do)
+    qr = torch.from_numpy(bf16_to_f32(qb).astype(np.float64)).requires_grad_(True)
+    dor = torch.from_numpy(bf16_to_f32(dob).astype(np.float64))
+    q, k, v = (qr[:, :T, i * H:(i + 1) * H].reshape(B, T, nh, hd).transpose(1, 2) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1)
+    o = (att @ v).transpose(1, 2).reshape(B, T, H)
+    o.backward(dor[:, :T])
+    d_qkv = torch.from_numpy(qb.view(np.int16)).cuda()
+    d_do = torch.from_numpy(dob.view(np.int16)).cuda()
+    ctx = torch.zeros(B, P, H, dtype=torch.int16, device="cuda")
+    dqkv = torch.zeros(B, P, 3 * H, dtype=torch.int16, device="cuda")
+    lse = torch.zeros(B * nh, Tp, device="cuda")
+    delta = torch.zeros(B * nh, Tp, device="cuda")
+    L = _lib.lib()
+    _lib.check(L.paa_attn_fwd(_lib.ptr(d_qkv), _lib.ptr(ctx), _lib.ptr(lse), B, T, P, Tp, H, nh, _lib.stream_ptr()))
+    _lib.check(L.paa_attn_bwd(_lib.ptr(d_qkv), _lib.ptr(ctx), _lib.ptr(lse), _lib.ptr(d_do), _lib.ptr(delta), _lib.ptr(dqkv),
+                              B, T, P, Tp, H, nh, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    og = bf16_to_f32(ctx.cpu().numpy().view(np.uint16))[:, :T]
+    dg = bf16_to_f32(dqkv.cpu().numpy().view(np.uint16))[:, :T]
+    e_o = rel_err(og, o.detach().numpy())
+    gref = qr.grad.numpy()[:, :T]
+    e_q, e_k, e_v = (rel_err(dg[..., i * H:(i + 1) * H], gref[..., i * H:(i + 1) * H]) for i in range(3))
+    print(f"attention T={T}: O {e_o:.2e} dQ {e_q:.2e} dK {e_k:.2e} dV {e_v:.2e}")
+    assert e_o < 1e-2 and e_q < 2e-2 and e_k < 2e-2 and e_v < 2e-2     # bf16 P / dS and bf16 outputs
+    assert float(ctx[:, T:].abs().max()) == 0 and float(dqkv[:, T:].abs().max()) == 0
