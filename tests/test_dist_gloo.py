@@ -1,0 +1,102 @@
+"""Data-parallel PGD step protocol on 2 CPU processes over gloo: each rank differentiates its shard
+of the utterances, ONE all-reduce(SUM) of the packed vector [grad(L) | loss, sum clean^2, TV(clean), ...] follows,
+then every rank applies the identical sign step and projection from the GLOBAL statistics.  Checked against the
+single-process full-batch oracle step; replicas must end bit-identical.  The model side is the oracle (CPU); the
+GPU path (training_utils/pgd.py) runs the same protocol with RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pgd as opgd, projections as OP, wav2vec2 as OW
+from paa_amd import arch as A, synth
+
+N_STATS = 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _project_global(p, args, stats, numel):
+    """project_snr / project_tv (projections.py:11-35, 56-66) from all-reduced clean statistics."""
+    if args.norm_type == "snr":
+        sp = stats[1] / numel
+        npow = torch.mean(p ** 2)
+        if 10 * torch.log10(sp / (npow + 1e-12)) >= args.snr_db:
+            return p
+        target = torch.sqrt(sp / (10 ** (args.snr_db / 10)) * numel)
+        cn = torch.norm(p.view(-1), p=2)
+        return p if cn < 1e-8 else p * (target / cn)
+    eps = args.tv_epsilon * stats[2]
+    tv = torch.sum(torch.abs(p[:, 1:] - p[:, :-1]))
+    return p * (eps / tv) if tv > eps else p
+
+
+def _worker(rank, world, port, norm, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    a = A.tiny()
+    B, L = 2, 8000                      # clips per rank
+    args = OP.default_args(norm_type=norm, snr_db=40.0, tv_epsilon=0.001)
+    sd = OW.to_torch(A.rule_weights(a))
+    clean = torch.from_numpy(synth.clean_audio(B, L, first_clip=rank * B))
+    texts = ["ab cd", "hello", "a b c", "xyz w"][rank * B:(rank + 1) * B]
+    labels = opgd.make_labels(texts, args, B)
+    p = torch.from_numpy(synth.perturbation(L) * np.float32(1e-2))
+    pr = p.clone().requires_grad_(True)
+    loss, _ = OW.forward(sd, a, (clean + pr).clamp(-1, 1), labels)
+    loss.backward()
+    packed = torch.zeros(L + N_STATS)
+    packed[:L] = pr.grad[0]
+    packed[L] = loss.detach()
+    packed[L + 1] = (clean ** 2).sum()
+    packed[L + 2] = (clean[:, 1:] - clean[:, :-1]).abs().sum()
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    with torch.no_grad():
+        p_new = p + args.lr * packed[:L].sign()[None]
+        p_new = _project_global(p_new, args, packed[L:], float(world * B * L))
+    gathered = [torch.zeros_like(p_new) for _ in range(world)]
+    dist.all_gather(gathered, p_new)
+    if rank == 0:
+        q.put((p_new.numpy(), float(packed[L]), all(torch.equal(g, gathered[0]) for g in gathered)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("norm", ["snr", "tv"])
+def test_two_rank_step_equals_full_batch(norm):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, norm, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    p_dp, loss_dp, identical = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert identical
+    # single process, full batch of 4 clips
+    a = A.tiny()
+    args = OP.default_args(norm_type=norm, snr_db=40.0, tv_epsilon=0.001)
+    sd = OW.to_torch(A.rule_weights(a))
+    clean = torch.from_numpy(synth.clean_audio(4, 8000))
+    labels = opgd.make_labels(["ab cd", "hello", "a b c", "xyz w"], args, 4)
+    p = torch.from_numpy(synth.perturbation(8000) * np.float32(1e-2))
+    ref = opgd.pgd_step(sd, a, args, clean, labels, p)
+    assert loss_dp == pytest.approx(float(ref["loss"]), rel=1e-5)
+    same = np.sign(ref["grad"].numpy()) != 0
+    diff = np.abs(p_dp - ref["p_new"].numpy())
+    # shards are summed in a different order than the full batch: allow sign flips only where |grad| ~ 0
+    assert (diff > 1e-6 * np.abs(ref["p_new"].numpy()).max() + 1e-9).mean() < 2e-3
