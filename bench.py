@@ -27,9 +27,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VARIANTS = {v: (f"k_gemm_bf<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'}>" if v & 16 else
+VARIANTS = {v: (f"k_gemm_bf<{'256' if v & 32 else '128'},{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'}>" if v & 16 else
                 f"k_gemm<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'},A{'k' if v & 2 else 'm'},B{'k' if v & 1 else 'n'}>")
-            for v in range(32)}
+            for v in range(64)}
 
 
 def parse():
@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--snr_db", type=float, default=40.0)
     ap.add_argument("--label_tokens", type=int, default=150)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_batch", type=int, default=2, help="clips in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu_batch", type=int, default=4, help="clips in the bounded CPU-baseline sample")
     ap.add_argument("--no_prof", action="store_true", help="skip the per-launch GEMM event timing")
     return ap.parse_args()
 
@@ -170,10 +170,10 @@ def main():
 
     roofline = None
     if prof_on:
-        out = (C.c_double * 96)()
+        out = (C.c_double * 192)()
         _lib.check(_lib.lib().paa_prof_read(out))
         _lib.lib().paa_prof_enable(0)
-        rows = [(v, out[3 * v], out[3 * v + 1], out[3 * v + 2]) for v in range(32) if out[3 * v] > 0]
+        rows = [(v, out[3 * v], out[3 * v + 1], out[3 * v + 2]) for v in range(64) if out[3 * v] > 0]
         rows.sort(key=lambda r: -r[2])
         if rows:
             v, n, ms, fl = rows[0]

@@ -140,11 +140,11 @@ int paa_model_layout(const paa_model* m, int i);  /* padded rows of conv layer i
 struct paa_gemm_desc;
 paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
 /* Measurement aid (bench.py roofline leg): HIP-event timing of every GEMM launch on its own stream.
- * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[32][3] =
+ * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[64][3] =
  * {launches, total ms, total algorithmic FLOP (2*M*N*K*batch)} per kernel variant
- * (bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig) and resets the counters. */
+ * (tileM256*32 + bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig) and resets. */
 paa_status paa_prof_enable(int max_launches);
-paa_status paa_prof_read(double* out96);
+paa_status paa_prof_read(double* out192);
 /* Fused attention (head_dim 64, bf16 planes as uint16): qkv (B*P, 3H) = Q|K|V, ctx/dctx (B*P, H), lse/delta (B*nh, Tp) */
 paa_status paa_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int P, int Tp, int H, int nh, void* stream);
 paa_status paa_attn_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, float* delta, void* dqkv,

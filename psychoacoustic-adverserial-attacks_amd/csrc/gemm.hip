@@ -32,12 +32,9 @@ struct GemmArgs {
 // ---- epilogue shared by both main loops ---------------------------------------------------------
 // Lane (lr, lh) of a wave holds column n = ... + lr and rows (e&3) + 8(e>>2) + 4 lh of each 32 x 32 accumulator.
 // All per-element offsets are 32-bit and relative to per-wave base pointers (tile-local row * ld + column).
-template <int BN, int MI = 2>
-__device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[MI][BN / 64], int m0, int n0, int z1, int z2,
-                                         int wm, int wn, int lr, int lh) {
-    constexpr int NJ = BN / 64;
-    const int mw = m0 + wm * (32 * MI) + 4 * lh;           // first row this lane owns
-    const int nw = n0 + wn * (BN / 2) + lr;                // first column this lane owns
+template <int NJ, int MI>
+__device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[MI][NJ], int mw, int nw, int z1, int z2) {
+    // mw / nw: first row / column this lane owns
     const int64_t coff = z1 * d.c_s1 + z2 * d.c_s2 + (int64_t)mw * d.ldc + nw;
     float* __restrict__ C = d.C ? d.C + coff : nullptr;
     float* __restrict__ Cp = d.C_pre ? d.C_pre + coff : nullptr;
@@ -52,48 +49,56 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
     const int act = d.act;
     const float alpha = d.alpha;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int dn = j * 32;
-        if (nw + dn >= d.N) continue;
-        const float bv = bias ? bias[dn] : 0.f;
+    for (int i = 0; i < MI; ++i) {
+        // per-accumulator-row-block base pointers: only the 16 in-block row offsets remain per-element scalars
+        const int64_t ro = (int64_t)(i * 32) * ldc;
+        float* __restrict__ Ci = C ? C + ro : nullptr;
+        float* __restrict__ Cpi = Cp ? Cp + ro : nullptr;
+        unsigned short* __restrict__ Cbi = Cb ? Cb + ro : nullptr;
+        unsigned short* __restrict__ Cbli = Cbl ? Cbl + ro : nullptr;
+        const float* __restrict__ auxi = aux ? aux + (int64_t)(i * 32) * ld_aux : nullptr;
+        const float* __restrict__ resi = res ? res + (int64_t)(i * 32) * ld_res : nullptr;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int j = 0; j < NJ; ++j) {
+            const int dn = j * 32;
+            if (nw + dn >= d.N) continue;
+            const float bv = bias ? bias[dn] : 0.f;
             float ax[16];
             if (act == PAA_ACT_GELU_GRAD) {          // issue the aux loads of this accumulator together
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
-                    ax[e] = (mw + dm < d.M) ? aux[dm * ld_aux + dn] : 0.f;
+                    const int dm = (e & 3) + 8 * (e >> 2);
+                    ax[e] = (mw + i * 32 + dm < d.M) ? auxi[dm * ld_aux + dn] : 0.f;
                 }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int dm = i * 32 + (e & 3) + 8 * (e >> 2);
-                if (mw + dm >= d.M) continue;
+                const int dm = (e & 3) + 8 * (e >> 2);
+                if (mw + i * 32 + dm >= d.M) continue;
                 float v = acc[i][j][e] * alpha + bv;
                 const int ci = dm * ldc + dn;
                 bool dead = false;
                 if (period > 0) {
-                    int rem = mrem0 + dm;
-                    if (rem >= period) rem = (period >= 32 * MI * 2) ? rem - period : rem % period;
+                    int rem = mrem0 + i * 32 + dm;
+                    if (rem >= period) rem = (period >= 32 * MI) ? rem - period : rem % period;
                     dead = rem >= d.row_valid;
                 }
                 if (act == PAA_ACT_GELU) {
-                    if (Cp) Cp[ci] = dead ? 0.f : v;
+                    if (Cpi) Cpi[ci] = dead ? 0.f : v;
                     v = gelu_f(v);
                 } else if (act == PAA_ACT_GELU_GRAD) {
                     v *= gelu_grad_f(ax[e]);
                 }
-                if (res) v += res[dm * ld_res + dn];
+                if (resi) v += resi[dm * ld_res + dn];
                 if (dead) v = 0.f;
-                if (C) {
-                    if (d.accumulate) v += C[ci];
-                    C[ci] = v;
+                if (Ci) {
+                    if (d.accumulate) v += Ci[ci];
+                    Ci[ci] = v;
                 }
-                if (Cb) {
+                if (Cbi) {
                     const unsigned short h = bf16_bits(v);
-                    Cb[ci] = h;
-                    if (Cbl) Cbl[ci] = bf16_bits(v - bf16_to_f32(h));
+                    Cbi[ci] = h;
+                    if (Cbli) Cbli[ci] = bf16_bits(v - bf16_to_f32(h));
                 }
             }
         }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(G_NT) void k_gemm(GemmArgs g) {
         __syncthreads();
     }
 
-    epilogue<BN>(d, acc, m0, n0, z1, z2, wm, wn, lr, lh);
+    epilogue<NJ, 2>(d, acc, m0 + wm * 64 + 4 * lh, n0 + wn * (BN / 2) + lr, z1, z2);
 }
 
 // ---- bf16-operand main loop ------------------------------------------------------------------------
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
         }
         __syncthreads();
     }
-    epilogue<BN, MI>(d, acc, m0, n0, z1, z2, wm, wn, lr, lh);
+    epilogue<NJ, MI>(d, acc, m0 + wm * (32 * MI) + 4 * lh, n0 + wn * (BN / 2) + lr, z1, z2);
 }
 
 template <int BN, int PREC>
@@ -461,7 +466,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     g.d = d;
     const bool narrow = d.N <= 64;
     const int bn = narrow ? 64 : 128;
-    const bool tall = d.operand_bf16 && !narrow && d.M >= 2048;     // 256 x 128 tile, 8 waves     // 256 x 128 tile: higher FLOP per LDS/L2 byte
+    const bool tall = d.operand_bf16 && !narrow && d.M >= 2048;     // 256 x 128 tile, 8 waves
     g.tiles_m = cdiv(d.M, tall ? 256 : G_BM);
     g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
@@ -469,7 +474,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
         g_prof.flops[g_prof.n] = 2.0 * d.M * d.N * (double)d.K * d.batch;
-        g_prof.variant[g_prof.n] = (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
+        g_prof.variant[g_prof.n] = (tall ? 32 : 0) + (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     }
     if (d.operand_bf16) {
         if (narrow) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 64, 1, 2>), grid, dim3(256), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 64, 0, 2>), grid, dim3(256), 0, st, g); }
@@ -498,12 +503,12 @@ extern "C" paa_status paa_prof_enable(int max_launches) {
     return PAA_OK;
 }
 
-// out[32][3] = per kernel variant (bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig): launches, total ms, total FLOP.
+// out[64][3] = per kernel variant (tileM256*32 + bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig).
 // Synchronises on the last recorded event.  Resets the counters.
 extern "C" paa_status paa_prof_read(double* out96) {
     using namespace paa;
     if (!out96) PAA_FAIL(PAA_ERR_ARG, "paa_prof_read: null");
-    for (int i = 0; i < 96; ++i) out96[i] = 0.0;
+    for (int i = 0; i < 192; ++i) out96[i] = 0.0;
     if (g_prof.n == 0) return PAA_OK;
     PAA_HIP(hipEventSynchronize(g_prof.ev[2 * g_prof.n - 1]));
     for (size_t i = 0; i < g_prof.n; ++i) {

@@ -60,7 +60,13 @@ def run(name, M, N, K, lda=None, act=0, pre=False, outf=True, outb=False, prec=0
 
 
 if __name__ == "__main__":
-    for prec in (0, 1):
+    import sys
+    modes = [int(a) for a in sys.argv[1:]] or [1]
+    for mode in modes:
+      for prec in (0, 1):
+        run("w1_t (N=768,K=3072) resid", 16000, 768, 3072, resid=True, prec=prec)
+        run("wqkv_t (N=768,K=2304) resid", 16000, 768, 2304, resid=True, prec=prec)
+        run("conv2 gelu pre+bf16 mask", 256000, 512, 1536, lda=1024, act=1, pre=True, outf=False, outb=True, rowmask=8000, prec=prec, iters=5)
         run("ffn1 plain f32 out", 16000, 3072, 768, prec=prec)
         run("ffn1 gelu pre+bf16 (model)", 16000, 3072, 768, act=1, pre=True, outf=False, outb=True, prec=prec)
         run("ffn2 resid f32", 16000, 768, 3072, resid=True, prec=prec)
