@@ -92,7 +92,8 @@ struct paa_model {
     // workspace
     float* arena = nullptr;
     int64_t arena_floats = 0;
-    float *gn_stats, *gn_bsums, *c0_part, *G;
+    float *gn_stats, *gn_bsums, *c0_part, *G = nullptr, *G1 = nullptr, *c0_Mx = nullptr, *c0_kc = nullptr;
+    Bf c0_w1H{nullptr, nullptr};
     float* gF[2];                    // f32 conv-stack gradients (conv0's input; every layer under the layer-norm variant)
     Bf gH[2];                        // bf16 conv-stack gradients (dgrad GEMM operands), with zero guard rows in front
     float* gz;
@@ -237,10 +238,14 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         const ConvL& c0 = m->conv[0];
         m->gn_stats = take((int64_t)B * c0.cout * 2); m->gn_bsums = take((int64_t)B * c0.cout * 2);
         m->c0_part = take((int64_t)B * conv0_chunks(c0.T) * c0.cout * 2);
-        m->G = take((int64_t)B * c0.P * c0.k);
+        if (a.feat_norm_layer) m->G = take((int64_t)B * c0.P * c0.k);
+        else {
+            m->G1 = take((int64_t)B * c0.P * 16); m->c0_Mx = take((int64_t)B * c0.k * c0.k); m->c0_kc = take((int64_t)B * 16);
+            m->c0_w1H = take_bf((int64_t)B * 16 * c0.cout);
+        }
         const int64_t gsz = ((int64_t)B * c0.P + 2 * GUARD) * maxC;
         for (int j = 0; j < 2; ++j) {
-            float* p = (a.feat_norm_layer || j == 0) ? take(gsz) : nullptr;
+            float* p = a.feat_norm_layer ? take(gsz) : nullptr;
             m->gF[j] = (pass && p) ? p + GUARD * maxC : nullptr;
             Bf h = take_bf(gsz);
             m->gH[j] = pass ? boff(h, GUARD * maxC) : NOBF;
@@ -533,7 +538,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
         const int ji = i & 1, jo = (i - 1) & 1;
         if (a.feat_norm_layer)                 // through LayerNorm_i to the raw conv output (f32 in, bf16 planes out)
             PAA_TRY(layernorm_bwd(m->gF[ji], c.cv, c.g, c.row_stats, nullptr, nullptr, nullptr, m->gH[ji], B * c.P, c.cout, st));
-        const bool out_f32 = a.feat_norm_layer || i == 1;     // next consumer is an element-wise kernel
+        const bool out_f32 = a.feat_norm_layer != 0;          // next consumer is an element-wise (LayerNorm backward) kernel
         for (int rho = 0; rho < c.s; ++rho) {
             const int Q = c.wdQ[rho];
             const int64_t ldo = (int64_t)c.s * c.cin;
@@ -556,7 +561,8 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
         ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
         ca.k = c.k; ca.stride = c.s; ca.w = c.w0; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
         ca.gn_stats = m->gn_stats; ca.gn_bsums = m->gn_bsums; ca.row_stats = c.row_stats; ca.dpre = m->gF[0]; ca.G = m->G;
-        PAA_TRY(conv0_backward(ca, a.feat_norm_layer, m->c0_part, grad, st));
+        ca.dpreb = m->gH[0]; ca.G1 = m->G1; ca.w1b = m->c0_w1H; ca.Mx = m->c0_Mx; ca.kc = m->c0_kc;
+        PAA_TRY(conv0_backward(ca, a.feat_norm_layer, m->prec, m->c0_part, grad, st));
     }
     return PAA_OK;
 }
@@ -633,8 +639,8 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
         else if (n == "logits") { p = m->logits; cnt = M * V; }
         else if (n == "dlogits") { p = m->dlogits; cnt = M * V; }
         else if (n == "nll") { p = m->nll; cnt = B; }
-        else if (n == "G") { p = m->G; cnt = (int64_t)B * c0.P * c0.k; }
-        else if (n == "gbuf0") { p = m->gF[0]; cnt = (int64_t)B * c0.P * c0.cout; }
+        else if (n == "G" && m->G) { p = m->G; cnt = (int64_t)B * c0.P * c0.k; }
+        else if (n == "gbuf0") { if (m->gF[0]) p = m->gF[0]; else pb = m->gH[0]; cnt = (int64_t)B * c0.P * c0.cout; }
         else if (n == "dh0") { p = m->dh0; cnt = M * H; }
         else if (n == "dfn") { p = m->dfn; cnt = M * a.conv_dim[nc - 1]; }
         else if (n == "dxa") { p = m->dxa; cnt = M * H; }

@@ -37,13 +37,18 @@ struct Conv0Args {
     float* gn_stats;         // group: (B, C, 2) mean, rstd over time
     float* gn_bsums;         // group backward: (B, C, 2) mean_t(dy), mean_t(dy * xhat)
     float* row_stats;        // layer: (B, P, 2) mean, rstd over channels
-    const float* dpre;       // backward: (B, P, C) gradient wrt `pre`
-    float* G;                // backward: (B, P, k) per-frame, per-tap input gradient
+    const float* dpre;       // backward, layer-norm variant: (B, P, C) f32 gradient wrt `pre`
+    Bf dpreb;                // backward, group-norm variant: the same gradient as bf16 planes (a GEMM operand)
+    float* G;                // backward, layer-norm variant: (B, P, k) per-frame, per-tap input gradient
+    float* G1;               // backward, group-norm variant: (B, P, 16) = dpre x W1_b (GEMM result)
+    Bf w1b;                  //   W1_b[j][c] = w[c][j] * gamma_c * rstd_bc as bf16 planes, (B, 16, C)
+    float* Mx;               //   (B, k, k)  sum_c W1_b[c][j] * s2_bc * rstd_bc * w[c][j']
+    float* kc;               //   (B, 16)    sum_c W1_b[c][j] * (s2_bc * rstd_bc * mean_bc - s1_bc)
     float* part;             // scratch partials
 };
 paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st);
 paa_status conv0_ln_forward(const Conv0Args& a, hipStream_t st);
-paa_status conv0_backward(const Conv0Args& a, int layer_norm, float* part, float* grad, hipStream_t st);
+paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, float* part, float* grad, hipStream_t st);
 int conv0_chunks(int T);
 
 int64_t ctc_work_floats_per_clip(int T, int V, int S_max);

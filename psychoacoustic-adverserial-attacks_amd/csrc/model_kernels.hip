@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                 a.pre[o] = y;
                 store_bf16(a.actb, o, gelu_f(y));
             } else {
-                const float dy = a.dpre[o];
+                float dy = bf16_to_f32(a.dpreb.hi[o]);
+                if (a.dpreb.lo) dy += bf16_to_f32(a.dpreb.lo[o]);
                 s1 += dy; s2 += dy * ((v - mean) * rstd);
             }
         }
@@ -221,16 +222,25 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
 }
 
 // Reduce the per-chunk partials in f64.  MODE 0: (sum, sumsq) -> (mean, rstd);  MODE 2: -> (s1/n, s2/n)
-__global__ void k_conv0_gn_finalize(const float* __restrict__ part, float* __restrict__ out, int B, int C,
-                                    int nchunk, int n, float eps, int mode) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
+__global__ __launch_bounds__(256) void k_conv0_gn_finalize(const float* __restrict__ part, float* __restrict__ out,
+                                                          int B, int C, int nchunk, int n, float eps, int mode) {
+    // 64 (b, c) pairs per block, 4 chunk-slices each (fixed summation order => reproducible)
+    __shared__ double sh1[4][64], sh2[4][64];
+    const int pair = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + pair;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        const size_t o = (((size_t)b * nchunk + k) * C + c) * 2;
-        s1 += (double)part[o]; s2 += (double)part[o + 1];
+    if (i < B * C) {
+        const int b = i / C, c = i % C;
+        for (int k = slice; k < nchunk; k += 4) {
+            const size_t o = (((size_t)b * nchunk + k) * C + c) * 2;
+            s1 += (double)part[o]; s2 += (double)part[o + 1];
+        }
     }
+    sh1[slice][pair] = s1; sh2[slice][pair] = s2;
+    __syncthreads();
+    if (slice != 0 || i >= B * C) return;
+    s1 = (sh1[0][pair] + sh1[1][pair]) + (sh1[2][pair] + sh1[3][pair]);
+    s2 = (sh2[0][pair] + sh2[1][pair]) + (sh2[2][pair] + sh2[3][pair]);
     if (mode == 0) {
         const double mean = s1 / n;
         double var = s2 / n - mean * mean;
@@ -378,6 +388,83 @@ __global__ void k_input_grad(Conv0Args a, float* __restrict__ grad) {
     grad[l] = total;
 }
 
+// GroupNorm backward of conv0 without touching the (B, T, C) gradient row by row:
+//   G[b,t,j] = sum_c w[c,j] dv[b,t,c],  dv = gamma rstd (dy - s1 - xhat s2),  xhat = (conv(x)[t,c] - mean) rstd
+//            = (dy[b,t,:] . W1_b[:,j]) + kc_b[j] - sum_j' Mx_b[j,j'] x[b, t*stride + j']
+// with W1_b[c,j] = w[c,j] gamma_c rstd_bc.  The first term is a GEMM over the bf16 planes of dy (per-clip B
+// operand); this kernel builds W1_b (bf16 planes, [16][C] per clip), Mx_b and kc_b.  One workgroup per clip.
+__global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a) {
+    __shared__ double red[256 / 64];
+    const int b = blockIdx.x;
+    float acc[10][11];
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+#pragma unroll
+        for (int q = 0; q < 11; ++q) acc[j][q] = 0.f;
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        const float mean = a.gn_stats[((size_t)b * a.C + c) * 2], rstd = a.gn_stats[((size_t)b * a.C + c) * 2 + 1];
+        const float s1 = a.gn_bsums[((size_t)b * a.C + c) * 2], s2 = a.gn_bsums[((size_t)b * a.C + c) * 2 + 1];
+        const float gr = a.gamma[c] * rstd;
+        float w[10], w1[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            w[j] = j < a.k ? a.w[c * a.k + j] : 0.f;
+            const float v = w[j] * gr;
+            const size_t o = ((size_t)b * 16 + j) * a.C + c;
+            const unsigned short h = bf16_bits(v);
+            a.w1b.hi[o] = h;
+            float vr = bf16_to_f32(h);
+            if (a.w1b.lo) { const unsigned short l = bf16_bits(v - vr); a.w1b.lo[o] = l; vr += bf16_to_f32(l); }
+            w1[j] = vr;                                   // the value the GEMM will actually multiply with
+        }
+        for (int j = 10; j < 16; ++j) { const size_t o = ((size_t)b * 16 + j) * a.C + c; a.w1b.hi[o] = 0; if (a.w1b.lo) a.w1b.lo[o] = 0; }
+        const float sr = s2 * rstd;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) acc[j][q] += w1[j] * sr * w[q];
+            acc[j][10] += w1[j] * (sr * mean - s1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const double t = block_sum<double, 256>((double)acc[j][q], red);
+            if (threadIdx.x == 0 && j < a.k) {
+                if (q < 10) { if (q < a.k) a.Mx[((size_t)b * a.k + j) * a.k + q] = (float)t; }
+                else a.kc[(size_t)b * 16 + j] = (float)t;
+            }
+        }
+}
+
+// grad[l] = sum_b mask_b[l] * sum_{(t, j): t*stride + j = l} G[b][t][j], G from the GEMM result G1 (see above)
+__global__ void k_input_grad_gn(Conv0Args a, float* __restrict__ grad) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.L) return;
+    float total = 0.f;
+    int t_hi = l / a.stride;
+    int t_lo = (l - a.k + 1 + a.stride - 1);
+    t_lo = t_lo <= 0 ? 0 : t_lo / a.stride;
+    if (t_hi > a.T - 1) t_hi = a.T - 1;
+    for (int b = 0; b < a.B; ++b) {
+        float gsum = 0.f;
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int j = l - t * a.stride;
+            float g = a.G1[((size_t)b * a.P + t) * 16 + j] + a.kc[(size_t)b * 16 + j];
+            const float* mx = a.Mx + ((size_t)b * a.k + j) * a.k;
+            for (int q = 0; q < a.k; ++q) g -= mx[q] * in_sample(a, b, t * a.stride + q);
+            gsum += g;
+        }
+        if (a.p && a.clamp) {
+            const float u = a.clean[(size_t)b * a.L + l] + a.p[l];
+            if (!(u >= -1.f && u <= 1.f)) gsum = 0.f;           // clamp backward: pass-through inside [-1, 1]
+        }
+        total += gsum;
+    }
+    grad[l] = total;
+}
+
 paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st) {
     if (a.k > 10 || a.C > 4096) PAA_FAIL(PAA_ERR_ARG, "conv0: kernel %d / channels %d unsupported", a.k, a.C);
     const int nchunk = cdiv(a.T, C0_TCH);
@@ -386,7 +473,7 @@ paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st) {
     b.part = part;
     hipLaunchKernelGGL(k_conv0_gn<0>, dim3(nchunk, a.B), dim3(256), lds, st, b);
     PAA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 256)), dim3(256), 0, st, (const float*)part,
+    hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 64)), dim3(256), 0, st, (const float*)part,
                        (float*)a.gn_stats, a.B, a.C, nchunk, a.T, a.eps, 0);
     PAA_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv0_gn<1>, dim3(nchunk, a.B), dim3(256), lds, st, b);
@@ -401,25 +488,36 @@ paa_status conv0_ln_forward(const Conv0Args& a, hipStream_t st) {
     return PAA_OK;
 }
 
-paa_status conv0_backward(const Conv0Args& a, int layer_norm, float* part, float* grad, hipStream_t st) {
+paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, float* part, float* grad, hipStream_t st) {
     if (a.k > 10 || a.C > 512) PAA_FAIL(PAA_ERR_ARG, "conv0 backward: kernel %d / channels %d unsupported", a.k, a.C);
     if (layer_norm) {
         hipLaunchKernelGGL(k_conv0_rows<C0_BWD_LN>, dim3(std::min(cdiv(a.P, 4), 512), a.B), dim3(256), 0, st, a);
         PAA_LAUNCH_CHECK();
-    } else {
-        const int nchunk = cdiv(a.T, C0_TCH);
-        const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10);
-        Conv0Args b = a;
-        b.part = part;
-        hipLaunchKernelGGL(k_conv0_gn<2>, dim3(nchunk, a.B), dim3(256), lds, st, b);
+        hipLaunchKernelGGL(k_input_grad, dim3(cdiv(a.L, 256)), dim3(256), 0, st, a, grad);
         PAA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 256)), dim3(256), 0, st, (const float*)part,
-                           (float*)a.gn_bsums, a.B, a.C, nchunk, a.T, a.eps, 2);
-        PAA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_conv0_rows<C0_BWD_GN>, dim3(std::min(cdiv(a.P, 4), 512), a.B), dim3(256), 0, st, a);
-        PAA_LAUNCH_CHECK();
+        return PAA_OK;
     }
-    hipLaunchKernelGGL(k_input_grad, dim3(cdiv(a.L, 256)), dim3(256), 0, st, a, grad);
+    const int nchunk = cdiv(a.T, C0_TCH);
+    const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10);
+    Conv0Args b = a;
+    b.part = part;
+    hipLaunchKernelGGL(k_conv0_gn<2>, dim3(nchunk, a.B), dim3(256), lds, st, b);     // s1 = mean_t dy, s2 = mean_t dy*xhat
+    PAA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 64)), dim3(256), 0, st, (const float*)part,
+                       (float*)a.gn_bsums, a.B, a.C, nchunk, a.T, a.eps, 2);
+    PAA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a);
+    PAA_LAUNCH_CHECK();
+    paa_gemm_desc d{};                    // G1[b] (P x 16) = dy[b] (P x C) . W1_b^T
+    d.operand_bf16 = 1; d.precision = precision;
+    d.A = reinterpret_cast<const float*>(a.dpreb.hi); d.A_lo = a.dpreb.lo;
+    d.B = reinterpret_cast<const float*>(a.w1b.hi); d.B_lo = a.w1b.lo;
+    d.C = a.G1;
+    d.M = a.P; d.N = 16; d.K = a.C; d.lda = a.C; d.ldb = a.C; d.ldc = 16;
+    d.a_kcontig = 1; d.b_kcontig = 1; d.alpha = 1.f;
+    d.batch = a.B; d.batch2 = 1; d.a_s1 = (int64_t)a.P * a.C; d.b_s1 = (int64_t)16 * a.C; d.c_s1 = (int64_t)a.P * 16;
+    PAA_TRY(gemm(d, st));
+    hipLaunchKernelGGL(k_input_grad_gn, dim3(cdiv(a.L, 256)), dim3(256), 0, st, a, grad);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
@@ -430,31 +528,38 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, float* part, float
 // LDS, every row stored for phase 3.  Phase 3: beta backwards; the posterior occupancy
 // gamma_t(s) = exp(alpha + beta + nll - lp) is summed per class with fixed-point LDS atomics (order
 // independent => bitwise reproducible) and dlogits[t][c] = scale * (softmax[t][c] - occ[c]).
-// The recursions run in float64: alpha + beta + nll cancels numbers of magnitude ~1e3, which in float32
-// (as torch's CPU kernel computes it) leaves ~1e-3 relative noise in the gradient; the work is tiny
-// (B * T * (2S+1) log-sum-exps), so the exact form costs nothing measurable.
+// The recursions ACCUMULATE in float64: alpha + beta + nll cancels numbers of magnitude ~1e3, which in float32
+// (as torch's CPU kernel computes it) leaves ~1e-3 relative noise in the gradient.  Only the bounded correction
+// log(sum exp(x_i - max)) in [0, log 3] is evaluated with the hardware float32 exp / log (absolute error ~1e-7 per
+// step), so the recursion costs a few instructions per element instead of software float64 transcendentals.
 __device__ __forceinline__ double lse2(double a, double b) {
     const double m = fmax(a, b);
     if (m == -INFINITY) return -INFINITY;
-    return m + log1p(exp(-fabs(a - b)));
+    return m + (double)log1pf(__expf((float)(-fabs(a - b))));
 }
 __device__ __forceinline__ double lse3(double a, double b, double c) {
     const double m = fmax(a, fmax(b, c));
     if (m == -INFINITY) return -INFINITY;
-    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+    return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m)));
 }
 
-__global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+// 512 threads: waves 0-3 run the alpha recursion forwards while waves 4-7 run the beta recursion backwards (one
+// workgroup barrier per time step serves both); every row of both is stored.  The gradient phase then needs no
+// workgroup barrier at all: each wave takes one frame, sums the posterior occupancy per class with fixed-point
+// LDS atomics into its own counters and writes that frame's gradient row.
+__global__ __launch_bounds__(512) void k_ctc(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                            int T, int Tpad, int V, int S_max, int blank, float gscale,
                                            float* __restrict__ nll_out, float* __restrict__ dlogits,
                                            float* __restrict__ work, int64_t work_per_clip, Bf dlb) {
     extern __shared__ __attribute__((aligned(16))) double smd[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int SPmax = 2 * S_max + 1;
-    double* prev = smd;                     // [SPmax]
-    double* cur = smd + SPmax;              // [SPmax]
-    int* lab = reinterpret_cast<int*>(smd + 2 * SPmax);   // [SPmax] extended labels
-    unsigned* occ = reinterpret_cast<unsigned*>(lab + SPmax);   // [V]
+    double* bufA0 = smd;                    // alpha rows (double buffered)
+    double* bufA1 = smd + SPmax;
+    double* bufB0 = smd + 2 * SPmax;        // beta rows
+    double* bufB1 = smd + 3 * SPmax;
+    int* lab = reinterpret_cast<int*>(smd + 4 * SPmax);          // [SPmax] extended labels
+    unsigned* occ = reinterpret_cast<unsigned*>(lab + SPmax);    // [8][V]
     __shared__ int s_len;
     __shared__ double s_nll;
 
@@ -462,22 +567,23 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
     double* wk = reinterpret_cast<double*>(work) + (size_t)b * work_per_clip;
     double* lp = wk;                                         // [T][V]
     double* alpha = lp + (size_t)T * V;                      // [T][SPmax]
+    double* beta = alpha + (size_t)T * SPmax;                // [T][SPmax]
 
     if (tid == 0) {
         int n = 0;
         for (int s = 0; s < S_max; ++s) if (labels[(size_t)b * S_max + s] >= 0) ++n;
         s_len = n;
     }
-    // phase 1: log-softmax, 32 lanes per frame
-    for (int t = tid >> 5; t < T; t += 8) {
+    // log-softmax, 32 lanes per frame
+    for (int t = tid >> 5; t < T; t += 16) {
         const int c = tid & 31;
         float mx = -INFINITY;
         for (int cc = c; cc < V; cc += 32) mx = fmaxf(mx, lg[(size_t)t * V + cc]);
         for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
-        double se = 0.0;
-        for (int cc = c; cc < V; cc += 32) se += exp((double)lg[(size_t)t * V + cc] - (double)mx);
+        float se = 0.f;
+        for (int cc = c; cc < V; cc += 32) se += __expf(lg[(size_t)t * V + cc] - mx);
         for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 32);
-        const double lz = (double)mx + log(se);
+        const double lz = (double)mx + (double)__logf(se);
         for (int cc = c; cc < V; cc += 32) lp[(size_t)t * V + cc] = (double)lg[(size_t)t * V + cc] - lz;
     }
     __syncthreads();
@@ -493,29 +599,48 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
         }
     }
     __syncthreads();
-    // phase 2: alpha
-    for (int s = tid; s < SP; s += 256) {
+    const bool fwd = tid < 256;
+    const int ht = tid & 255;
+    double* prev = fwd ? bufA0 : bufB0;
+    double* cur = fwd ? bufA1 : bufB1;
+    // t = 0 (alpha) / t = T-1 (beta)
+    for (int s = ht; s < SP; s += 256) {
         double v = -INFINITY;
-        if (s == 0) v = lp[blank];
-        else if (s == 1) v = lp[lab[1]];
+        if (fwd) {
+            if (s == 0) v = lp[blank];
+            else if (s == 1) v = lp[lab[1]];
+            alpha[s] = v;
+        } else {
+            if (s == SP - 1 || s == SP - 2) v = lp[(size_t)(T - 1) * V + lab[s]];
+            beta[(size_t)(T - 1) * SPmax + s] = v;
+        }
         prev[s] = v;
-        alpha[s] = v;
     }
     __syncthreads();
-    for (int t = 1; t < T; ++t) {
-        for (int s = tid; s < SP; s += 256) {
+    for (int i = 1; i < T; ++i) {
+        const int t = fwd ? i : T - 1 - i;
+        for (int s = ht; s < SP; s += 256) {
             const int l = lab[s];
-            const double a0 = prev[s];
-            const double a1 = s >= 1 ? prev[s - 1] : -INFINITY;
-            const double a2 = (s >= 2 && l != blank && l != lab[s - 2]) ? prev[s - 2] : -INFINITY;
-            const double v = lse3(a0, a1, a2) + lp[(size_t)t * V + l];
+            double v;
+            if (fwd) {
+                const double a0 = prev[s];
+                const double a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+                const double a2 = (s >= 2 && l != blank && l != lab[s - 2]) ? prev[s - 2] : -INFINITY;
+                v = lse3(a0, a1, a2) + lp[(size_t)t * V + l];
+                alpha[(size_t)t * SPmax + s] = v;
+            } else {
+                const double b0 = prev[s];
+                const double b1 = s + 1 < SP ? prev[s + 1] : -INFINITY;
+                const double b2 = (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l) ? prev[s + 2] : -INFINITY;
+                v = lse3(b0, b1, b2) + lp[(size_t)t * V + l];
+                beta[(size_t)t * SPmax + s] = v;
+            }
             cur[s] = v;
-            alpha[(size_t)t * SPmax + s] = v;
         }
         __syncthreads();
         double* tmp = prev; prev = cur; cur = tmp;
     }
-    if (tid == 0) {
+    if (tid == 0) {        // alpha_{T-1} is in the forward group's `prev` (thread 0 belongs to it)
         const double l1 = prev[SP - 1];
         const double l2 = SP >= 2 ? prev[SP - 2] : -INFINITY;
         const double nll = -lse2(l1, l2);
@@ -527,52 +652,35 @@ __global__ __launch_bounds__(256) void k_ctc(const float* __restrict__ logits, c
     const double nll = s_nll;
     float* dl = dlogits + (size_t)b * Tpad * V;
     const size_t dlo = (size_t)b * Tpad * V;
-    for (int i = tid; i < (Tpad - T) * V; i += 256) { dl[(size_t)T * V + i] = 0.f; store_bf16(dlb, dlo + (size_t)T * V + i, 0.f); }   // pad frames
+    for (int i = tid; i < (Tpad - T) * V; i += 512) { dl[(size_t)T * V + i] = 0.f; store_bf16(dlb, dlo + (size_t)T * V + i, 0.f); }   // pad frames
     if (!(nll < INFINITY)) {      // infeasible alignment: zero_infinity=False propagates non-finite gradients
-        for (int i = tid; i < T * V; i += 256) { dl[i] = NAN; store_bf16(dlb, dlo + i, NAN); }
+        for (int i = tid; i < T * V; i += 512) { dl[i] = NAN; store_bf16(dlb, dlo + i, NAN); }
         return;
     }
-    // phase 3: beta + gradient.  beta_{T-1}: last blank and last label.
-    for (int s = tid; s < SP; s += 256) {
-        double v = -INFINITY;
-        if (s == SP - 1 || s == SP - 2) v = lp[(size_t)(T - 1) * V + lab[s]];
-        prev[s] = v;
-    }
-    __syncthreads();
-    for (int t = T - 1; t >= 0; --t) {
-        if (t < T - 1) {
-            for (int s = tid; s < SP; s += 256) {
-                const int l = lab[s];
-                const double b0 = prev[s];
-                const double b1 = s + 1 < SP ? prev[s + 1] : -INFINITY;
-                const double b2 = (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l) ? prev[s + 2] : -INFINITY;
-                cur[s] = lse3(b0, b1, b2) + lp[(size_t)t * V + l];
-            }
-            __syncthreads();
-            double* tmp = prev; prev = cur; cur = tmp;
-        }
-        for (int c = tid; c < V; c += 256) occ[c] = 0u;
-        __syncthreads();
-        for (int s = tid; s < SP; s += 256) {
+    // gradient: one wave per frame, no workgroup barriers
+    const int wave = tid >> 6, lane = tid & 63;
+    unsigned* wocc = occ + wave * V;
+    for (int t = wave; t < T; t += 8) {
+        for (int c = lane; c < V; c += 64) wocc[c] = 0u;
+        for (int s = lane; s < SP; s += 64) {
             const int l = lab[s];
-            const double g = exp(alpha[(size_t)t * SPmax + s] + prev[s] + nll - lp[(size_t)t * V + l]);
-            const unsigned q = (unsigned)(fmin(g, 2.0) * 1073741824.0 + 0.5);
-            if (q) atomicAdd(&occ[l], q);
+            const float g = __expf((float)(alpha[(size_t)t * SPmax + s] + beta[(size_t)t * SPmax + s] + nll - lp[(size_t)t * V + l]));
+            const unsigned q = (unsigned)(fminf(g, 2.f) * 1073741824.f + 0.5f);
+            if (q) atomicAdd(&wocc[l], q);
         }
-        __syncthreads();
-        for (int c = tid; c < V; c += 256) {
-            const float gv = gscale * (float)(exp(lp[(size_t)t * V + c]) - (double)occ[c] * (1.0 / 1073741824.0));
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // this wave's LDS atomics before its reads below
+        for (int c = lane; c < V; c += 64) {
+            const float gv = gscale * (__expf((float)lp[(size_t)t * V + c]) - (float)wocc[c] * (1.f / 1073741824.f));
             dl[(size_t)t * V + c] = gv;
             store_bf16(dlb, dlo + (size_t)t * V + c, gv);
         }
-        __syncthreads();
     }
 }
 
-// work size in FLOATS per clip (the kernel stores doubles): lp [T][V] + alpha [T][2S+1]
+// work size in FLOATS per clip (the kernel stores doubles): lp [T][V] + alpha, beta [T][2S+1]
 int conv0_chunks(int T) { return cdiv(T, C0_TCH); }
 
-int64_t ctc_work_floats_per_clip(int T, int V, int S_max) { return 2 * ((int64_t)T * V + (int64_t)T * (2 * S_max + 1)); }
+int64_t ctc_work_floats_per_clip(int T, int V, int S_max) { return 2 * ((int64_t)T * V + 2 * (int64_t)T * (2 * S_max + 1)); }
 
 paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
                float grad_scale, float* nll, float* dlogits, Bf dlb, float* work, hipStream_t st) {
@@ -580,8 +688,9 @@ paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpa
     if (V > 256) PAA_FAIL(PAA_ERR_SIZE, "ctc: vocab %d > 256", V);
     if ((uintptr_t)work & 7) PAA_FAIL(PAA_ERR_ARG, "ctc: work buffer must be 8-byte aligned");
     const int SPmax = 2 * S_max + 1;
-    const size_t lds = sizeof(double) * 2 * (size_t)SPmax + sizeof(int) * ((size_t)SPmax + V);
-    hipLaunchKernelGGL(k_ctc, dim3(B), dim3(256), lds, st, logits, labels, T, Tpad, V, S_max, blank, grad_scale, nll,
+    const size_t lds = sizeof(double) * 4 * (size_t)SPmax + sizeof(int) * ((size_t)SPmax + 8 * V);
+    if (lds > 160 * 1024) PAA_FAIL(PAA_ERR_SIZE, "ctc: label capacity %d needs %zu bytes of LDS", S_max, lds);
+    hipLaunchKernelGGL(k_ctc, dim3(B), dim3(512), lds, st, logits, labels, T, Tpad, V, S_max, blank, grad_scale, nll,
                        dlogits, work, ctc_work_floats_per_clip(T, V, S_max) / 2, dlb);
     PAA_LAUNCH_CHECK();
     return PAA_OK;

@@ -240,7 +240,7 @@ def test_ctc(T, S_max, lens):
     e1 = rel_err(out_nll.cpu()[fin], nll.detach()[fin])
     e2 = rel_err(dl.cpu()[fin], lr.grad[fin])
     print(f"ctc T={T}: nll {e1:.2e} grad {e2:.2e}")
-    assert e1 < 2e-6 and e2 < 2e-6
+    assert e1 < 2e-6 and e2 < 1e-5
 
 
 @pytest.mark.parametrize("T,B,nh", [(499, 2, 3), (70, 1, 2), (32, 1, 1), (131, 2, 2)])
