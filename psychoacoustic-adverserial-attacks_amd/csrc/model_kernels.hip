@@ -617,28 +617,47 @@ __global__ __launch_bounds__(512) void k_ctc(const float* __restrict__ logits, c
         prev[s] = v;
     }
     __syncthreads();
+    // the emission log-probability of the NEXT step is fetched while this step computes (keeps the ~L2 latency
+    // of the lp read out of the serial alpha / beta chain); slots cover (2S+1) <= 1024
+    double em[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int s = ht + 256 * q;
+        em[q] = (s < SP && T > 1) ? lp[(size_t)(fwd ? 1 : T - 2) * V + lab[s]] : 0.0;
+    }
     for (int i = 1; i < T; ++i) {
         const int t = fwd ? i : T - 1 - i;
+        double emn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = ht + 256 * q;
+            const int tn = fwd ? i + 1 : T - 2 - i;
+            emn[q] = (s < SP && i + 1 < T) ? lp[(size_t)tn * V + lab[s]] : 0.0;
+        }
         for (int s = ht; s < SP; s += 256) {
             const int l = lab[s];
+            const int q = (s - ht) >> 8;
+            const double e = q == 0 ? em[0] : q == 1 ? em[1] : q == 2 ? em[2] : q == 3 ? em[3] : lp[(size_t)t * V + l];
             double v;
             if (fwd) {
                 const double a0 = prev[s];
                 const double a1 = s >= 1 ? prev[s - 1] : -INFINITY;
                 const double a2 = (s >= 2 && l != blank && l != lab[s - 2]) ? prev[s - 2] : -INFINITY;
-                v = lse3(a0, a1, a2) + lp[(size_t)t * V + l];
+                v = lse3(a0, a1, a2) + e;
                 alpha[(size_t)t * SPmax + s] = v;
             } else {
                 const double b0 = prev[s];
                 const double b1 = s + 1 < SP ? prev[s + 1] : -INFINITY;
                 const double b2 = (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l) ? prev[s + 2] : -INFINITY;
-                v = lse3(b0, b1, b2) + lp[(size_t)t * V + l];
+                v = lse3(b0, b1, b2) + e;
                 beta[(size_t)t * SPmax + s] = v;
             }
             cur[s] = v;
         }
         __syncthreads();
         double* tmp = prev; prev = cur; cur = tmp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) em[q] = emn[q];
     }
     if (tid == 0) {        // alpha_{T-1} is in the forward group's `prev` (thread 0 belongs to it)
         const double l1 = prev[SP - 1];
