@@ -180,8 +180,18 @@ def main():
             # split mode issues 3 MFMA per algorithmic product; `achieved` counts ALGORITHMIC flops only
             achieved = fl / (ms * 1e-3) / 1e12
             peak = 2500.0
+            # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+            # this same command (profiles/r1_hbm_traffic_pmc.json, FETCH_SIZE doubled per the gfx950 correction); null if absent
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")) as f:
+                    for k in json.load(f)["kernels"]:
+                        if VARIANTS[v].startswith("k_gemm_bf<256") and "k_gemm_bf<256, 128, 0, 4>" in k["kernel"] and ar.dtype == "bf16":
+                            traffic = k["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roofline = {"bound": "mfma", "kernel": VARIANTS[v], "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": None, "launches": int(n),
+                        "frac": round(achieved / peak, 4), "traffic": traffic, "launches": int(n),
                         "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step": round(ms * 1e-3 / dt, 4),
                         "all_gemm_variants": [{"kernel": VARIANTS[r[0]], "launches": int(r[1]), "ms": round(r[2], 3),
                                                "tflops": round(r[3] / (r[2] * 1e-3) / 1e12, 2)} for r in rows]}

@@ -466,9 +466,9 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     g.d = d;
     const bool narrow = d.N <= 64;
     const int bn = narrow ? 64 : 128;
-    // 256 x 128 tile (8 waves, 2 workgroups per CU) once there are enough of them to fill the chip a few times over;
-    // otherwise 128 x 128 (4 waves, 3 per CU): measured 4-8 % faster on the M = 16000, N <= 2304 transformer products
-    const bool tall = d.operand_bf16 && !narrow && (int64_t)cdiv(d.M, 256) * cdiv(d.N, 128) * d.batch >= 1400;
+    // 256 x 128 tile (8 waves, 2 workgroups per CU) for every large-M product; 128 x 128 (4 waves) was 4-8 % faster on
+    // the isolated M = 16000, N <= 2304 shapes but made no difference inside the step (A/B on one device)
+    const bool tall = d.operand_bf16 && !narrow && d.M >= 2048;
     g.tiles_m = cdiv(d.M, tall ? 256 : G_BM);
     g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
