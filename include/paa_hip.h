@@ -129,6 +129,11 @@ paa_status paa_model_fwd_bwd(paa_model* m, const float* d_clean, const float* d_
                              int B, int S_max, int direction, float* d_grad, float* d_logits, float* d_stats,
                              void* stream);
 
+/* Forward + CTC loss only (core/loss_helpers.py:46-57 get_loss, training_utils/evaluation.py:5-31): clamp = 0 adds p
+ * without clamping as the reference's evaluation does (evaluation.py:16); d_p may be NULL (clean evaluation). */
+paa_status paa_model_forward(paa_model* m, const float* d_clean, const float* d_p, int clamp, const int32_t* d_labels,
+                             int B, int S_max, float* d_logits, float* d_stats, void* stream);
+
 /* Diagnostics for tests: synchronous copy of a named internal activation to the host (see csrc/model.hip);
  * returns the number of floats the buffer holds for batch B (0 = unknown name, <0 = HIP error). */
 int64_t paa_model_debug_read(paa_model* m, const char* name, float* host, int64_t max_floats, int B);

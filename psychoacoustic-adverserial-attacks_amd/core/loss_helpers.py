@@ -50,7 +50,7 @@ def get_loss_for_training(model, data, target_texts, processor, args):
     with HF's ctc_loss_reduction='sum'.  Forward only — the PGD step gets its gradient from
     ``training_utils.pgd.PgdStepper`` in the same launch sequence."""
     labels = make_labels(target_texts, processor, args, len(data))
-    r = model.fwd_bwd(data, None, labels, direction=+1, want_grad=False, want_logits=True)
+    r = model.forward(data, None, labels)
     return r["loss"], r["logits"]
 
 
@@ -62,7 +62,7 @@ def get_logits(batch_waveforms, processor, args, model):
     normalisation before the forward; that normalisation is done here with torch on the device."""
     x = batch_waveforms.to(model.device, torch.float32)
     x = (x - x.mean(dim=-1, keepdim=True)) / torch.sqrt(x.var(dim=-1, keepdim=True, unbiased=False) + 1e-7)
-    return model.fwd_bwd(x.contiguous(), None, None, want_grad=False, want_logits=True)["logits"]
+    return model.forward(x.contiguous(), None, None)["logits"]
 
 
 def greedy_decode_ids(pred_ids) -> list:

@@ -592,6 +592,28 @@ extern "C" paa_status paa_model_fwd_bwd(paa_model* m, const float* d_clean, cons
     return PAA_OK;
 }
 
+// Forward + CTC loss only, with explicit control of the clamp: the reference's evaluation adds p WITHOUT clamping
+// (training_utils/evaluation.py:16), its training step clamps (train.py:136).
+extern "C" paa_status paa_model_forward(paa_model* m, const float* d_clean, const float* d_p, int clamp, const int32_t* d_labels,
+                                        int B, int S_max, float* d_logits, float* d_stats, void* stream) {
+    if (!m || !d_clean) PAA_FAIL(PAA_ERR_ARG, "paa_model_forward: null argument");
+    if (B < 1 || B > m->Bmax) PAA_FAIL(PAA_ERR_SIZE, "batch %d exceeds max_batch %d", B, m->Bmax);
+    if (d_labels && (S_max < 1 || S_max > m->S_cap)) PAA_FAIL(PAA_ERR_SIZE, "S_max=%d exceeds capacity %d", S_max, m->S_cap);
+    hipStream_t st = (hipStream_t)stream;
+    PAA_TRY(forward(m, d_clean, d_p, (d_p && clamp) ? 1 : 0, B, st));
+    const int V = m->a.vocab;
+    if (d_logits) {
+        hipLaunchKernelGGL(k_copy_logits, dim3(std::min(cdiv((int64_t)B * m->T * V, 256), 2048)), dim3(256), 0, st,
+                           (const float*)m->logits, d_logits, B, m->T, m->P, V);
+        PAA_LAUNCH_CHECK();
+    }
+    if (d_labels) {
+        PAA_TRY(ctc(m->logits, d_labels, B, m->T, m->P, V, S_max, m->a.blank, 1.f, m->nll, nullptr, NOBF, m->ctc_work, st));
+        if (d_stats) PAA_TRY(sum_small(m->nll, B, d_stats, st));
+    }
+    return PAA_OK;
+}
+
 // sizeof of every struct that crosses the ABI, so the host binding can verify its layout.
 extern "C" void paa_abi_sizes(int32_t* out4) {
     out4[0] = (int32_t)sizeof(paa_params);

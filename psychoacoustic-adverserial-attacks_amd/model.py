@@ -216,6 +216,22 @@ class PaaModel:
                                                     _lib.ptr(grad), _lib.ptr(logits), _lib.ptr(stats), _lib.stream_ptr()))
         return dict(loss=stats[0], logits=logits, grad=grad, stats=stats, labels=lab)
 
+    def forward(self, clean, p, labels, clamp=False, want_logits=True):
+        """Forward + CTC loss only.  ``clamp=False`` composes ``clean + p`` as the reference's evaluation does
+        (evaluation.py:16); ``p=None`` evaluates the clean batch.  Returns dict(loss, logits)."""
+        B, L = clean.shape
+        if L != self.length:
+            raise ValueError(f"Loaded perturbation length {L} != expected {self.length}")
+        dev = self.device
+        lab = None if labels is None else labels.to(device=dev, dtype=torch.int32).contiguous()
+        logits = torch.empty(B, self.frames, self.arch.vocab_size, dtype=torch.float32, device=dev) if want_logits else None
+        stats = torch.zeros(8, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().paa_model_forward(self.h, _lib.ptr(clean), _lib.ptr(p), int(bool(clamp)), _lib.ptr(lab), B,
+                                                    0 if lab is None else lab.shape[1], _lib.ptr(logits), _lib.ptr(stats),
+                                                    _lib.stream_ptr()))
+        return dict(loss=stats[0], logits=logits)
+
     def debug_read(self, name: str, B: int) -> np.ndarray:
         """Copy a named internal activation to the host (tests / diagnostics only)."""
         n = _lib.lib().paa_model_debug_read(self.h, name.encode(), None, 0, B)

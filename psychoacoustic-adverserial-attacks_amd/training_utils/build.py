@@ -79,3 +79,136 @@ def synthetic_loader(args, batch: int, length: int, steps: int, rank: int = 0, w
             texts.append(" ".join(words[int(v * len(words))] for v in u))
         out.append((x, texts))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ runner setup
+def attack_size_string(args) -> str:
+    """build.py:235-247: the epsilon that names the run directory."""
+    sizes = {"min_max_freqs": f"{args.min_freq_attack}", "fletcher_munson": f"{args.fm_epsilon}",
+             "max_phon": f"{args.max_phon_level}", "l2": f"{args.l2_size}", "linf": f"{args.linf_size}",
+             "snr": f"{args.snr_db}", "tv": f"{args.tv_epsilon}"}
+    first = str(args.norm_type).split("+")[0]
+    if first not in sizes:
+        raise ValueError(f"Unsupported norm_type: {args.norm_type}")
+    return sizes[first]
+
+
+def create_logger(args, logs_root=None):
+    """build.py:233-286: derive save_dir = <logs>/<mode>/<dataset>/<norm>_<size>_<mode>_<opt>, set up the "asr_attack"
+    logger (rotating file + console) and discover a resumable checkpoint: an existing perturbation.pt in save_dir makes
+    the run resume from it at results.json["epoch"] (unless --small_data), overriding --resume_from as the reference does."""
+    import json
+    import logging
+    from logging.handlers import RotatingFileHandler
+    args.attack_size_string = attack_size_string(args)
+    root = logs_root or getattr(args, "logs_dir", None) or os.path.join(os.getcwd(), "logs")
+    args.save_dir = os.path.join(root, args.attack_mode, args.dataset,
+                                 f"{args.norm_type}_{args.attack_size_string}_{args.attack_mode}_{args.optimizer_type}")
+    os.makedirs(args.save_dir, exist_ok=True)
+    logger = logging.getLogger("asr_attack")
+    logger.setLevel(logging.INFO)
+    logger.handlers.clear()
+    fmt = logging.Formatter("%(asctime)s | %(levelname)s | %(message)s")
+    fh = RotatingFileHandler(os.path.join(args.save_dir, "train.log"), maxBytes=5 * 1024 * 1024, backupCount=3)
+    fh.setFormatter(fmt)
+    logger.addHandler(fh)
+    if not getattr(args, "silent", False):
+        ch = logging.StreamHandler()
+        ch.setFormatter(fmt)
+        logger.addHandler(ch)
+    args.was_preempted = os.path.exists(os.path.join(args.save_dir, "perturbation.pt"))
+    args.had_checkpoint = args.was_preempted
+    chkpt_epoch = 0
+    results_path = os.path.join(args.save_dir, "results.json")
+    if os.path.exists(results_path):
+        try:
+            with open(results_path) as f:
+                chkpt_epoch = int(json.load(f).get("epoch", 0))
+        except Exception as e:          # noqa: BLE001
+            logger.warning("Failed to read results.json: %s", e)
+    if args.was_preempted and not getattr(args, "small_data", False):
+        args.resume = True
+        args.resume_from = os.path.join(args.save_dir, "perturbation.pt")
+        logger.info("Resuming from checkpoint: %s (epoch=%d)", args.resume_from, chkpt_epoch)
+    else:
+        args.resume = False
+    return logger, max(chkpt_epoch, 0)
+
+
+def percentile_length(lengths, q: float) -> int:
+    """build.py:41-61: the clip length every utterance is cropped / right-zero-padded to (q-quantile of the lengths)."""
+    return int(np.quantile(np.asarray(lengths, dtype=np.int64), q))
+
+
+def collate_fixed(waves, length: int) -> torch.Tensor:
+    """build.py:186-191: crop or right-zero-pad each waveform to ``length`` -> (N, length) float32."""
+    out = torch.zeros(len(waves), length, dtype=torch.float32)
+    for i, w in enumerate(waves):
+        w = torch.as_tensor(w, dtype=torch.float32).reshape(-1)
+        n = min(length, w.numel())
+        out[i, :n] = w[:n]
+    return out
+
+
+def _batches(x, texts, batch_size):
+    return [(x[i:i + batch_size], texts[i:i + batch_size]) for i in range(0, len(texts), batch_size)]
+
+
+def load_local_dataset(data_dir: str, sr: int):
+    """A local directory of ``*.wav`` files with transcripts in ``*.trans.txt`` (LibriSpeech style: "<utt-id> TEXT")
+    or ``transcripts.csv`` ("file,text").  No network, no torchaudio: PCM wav via the stdlib."""
+    import csv
+    import glob
+    from . import save
+    texts = {}
+    for f in glob.glob(os.path.join(data_dir, "**", "*.trans.txt"), recursive=True):
+        for line in open(f):
+            k, _, t = line.strip().partition(" ")
+            texts[k] = t
+    csvp = os.path.join(data_dir, "transcripts.csv")
+    if os.path.exists(csvp):
+        for row in csv.reader(open(csvp)):
+            if len(row) >= 2:
+                texts[os.path.splitext(os.path.basename(row[0]))[0]] = row[1]
+    waves, out_texts = [], []
+    for f in sorted(glob.glob(os.path.join(data_dir, "**", "*.wav"), recursive=True)):
+        key = os.path.splitext(os.path.basename(f))[0]
+        if key not in texts:
+            continue
+        x, fsr = save.load_audio(f)
+        if fsr != sr:
+            raise ValueError(f"{f}: sample rate {fsr} != --sr {sr}")
+        waves.append(x)
+        out_texts.append(texts[key])
+    if not waves:
+        raise ValueError(f"no (wav, transcript) pairs found under {data_dir}")
+    return waves, out_texts
+
+
+def create_data_loaders(args):
+    """build.py:104-220 without the network: --data_dir (local wavs) or synthetic clips; fixed-length collate at the
+    ``relative_audio_length`` quantile; 80/10/10 split; --small_data keeps ~1 % (at least 3 batches' worth).
+    Returns (train, eval, test) lists of (batch (B, L) float32 CPU tensor, list[str]) and the clip length."""
+    bs = int(args.batch_size)
+    data_dir = getattr(args, "data_dir", None)
+    if data_dir:
+        waves, texts = load_local_dataset(data_dir, int(args.sr))
+        length = percentile_length([len(w) for w in waves], float(args.relative_audio_length))
+        x = collate_fixed(waves, length)
+    else:
+        length = int(round(float(getattr(args, "audio_seconds", 10.0)) * int(args.sr)))
+        n = bs * int(getattr(args, "steps_per_epoch", 4)) * 10 // 8 + 2 * bs
+        x = torch.from_numpy(synth.clean_audio(n, length, seed=int(args.seed)))
+        words = ["the", "quick", "brown", "fox", "jumps", "over", "a", "lazy", "dog", "and", "runs", "away"]
+        texts = []
+        for i in range(n):
+            u = synth.uniform(synth.key_of(f"txt{i}", int(args.seed)), 12)
+            texts.append(" ".join(words[int(v * len(words))] for v in u))
+    n = len(texts)
+    if getattr(args, "small_data", False):
+        n = min(n, max(3 * bs, n // 100))
+    n_tr, n_ev = int(0.8 * n), int(0.1 * n)
+    tr = _batches(x[:n_tr], texts[:n_tr], bs)
+    ev = _batches(x[n_tr:n_tr + n_ev], texts[n_tr:n_tr + n_ev], bs)
+    te = _batches(x[n_tr + n_ev:n], texts[n_tr + n_ev:n], bs)
+    return tr, ev, te, length

@@ -61,4 +61,7 @@ def create_arg_parser():
                         help='MFMA operand precision: bf16, or fp32 = split-bf16 (3 passes), fp32-parity')
     parser.add_argument('--audio_seconds', type=float, default=10.0, help='clip length for synthetic data')
     parser.add_argument('--steps_per_epoch', type=int, default=4, help='synthetic batches per epoch')
+    parser.add_argument('--data_dir', type=str, default=None, help='local directory of wav files + transcripts (no download)')
+    parser.add_argument('--logs_dir', type=str, default=None, help='root of the run directories (default ./logs)')
+    parser.add_argument('--silent', action='store_true')
     return parser
