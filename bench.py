@@ -84,11 +84,17 @@ def main():
     if world != ar.gpus:
         if world == 1 and ar.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    ndev = max(torch.cuda.device_count(), 1)
+    local = local % ndev                       # one rank per GPU; the modulo only matters for single-GPU rehearsals
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("PAA_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" for rehearsals on one GPU
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     import __graft_entry__
     if rank == 0:

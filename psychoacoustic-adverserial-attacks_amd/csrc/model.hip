@@ -267,7 +267,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         }
         m->logits = take((int64_t)m->M * V); m->dlogits = take((int64_t)m->M * V); m->dlogitsH = take_bf((int64_t)m->M * V);
         m->nll = take(B);
-        m->S_cap = std::max(1, std::min(4000, m->T));     // labels longer than T_e are infeasible anyway
+        m->S_cap = std::min(2047, std::max(64, m->T));    // labels longer than T_e are infeasible (infinite CTC loss) but legal
         m->ctc_work = take((int64_t)B * ctc_work_floats_per_clip(m->T, V, m->S_cap));
         m->dxa = take(MH); m->dxaH = take_bf(MH); m->dxb = take(MH); m->dxbH = take_bf(MH);
         m->dqkvH = take_bf(3 * MH);

@@ -201,8 +201,9 @@ def create_data_loaders(args):
         x = torch.from_numpy(synth.clean_audio(n, length, seed=int(args.seed)))
         words = ["the", "quick", "brown", "fox", "jumps", "over", "a", "lazy", "dog", "and", "runs", "away"]
         texts = []
+        n_words = max(1, min(24, length // 320 // 12))       # ~1 character per 3 encoder frames: CTC-feasible at any length
         for i in range(n):
-            u = synth.uniform(synth.key_of(f"txt{i}", int(args.seed)), 12)
+            u = synth.uniform(synth.key_of(f"txt{i}", int(args.seed)), n_words)
             texts.append(" ".join(words[int(v * len(words))] for v in u))
     n = len(texts)
     if getattr(args, "small_data", False):
