@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_batch", type=int, default=4, help="clips in the bounded CPU-baseline sample")
     ap.add_argument("--no_prof", action="store_true", help="skip the per-launch GEMM event timing")
+    ap.add_argument("--graph", action="store_true", help="replay the step from captured hipGraphs (single rank; implies --no_prof)")
     return ap.parse_args()
 
 
@@ -132,9 +133,20 @@ def main():
     done = [torch.cuda.Event() for _ in range(2)]
     bookkeeping = {"loss": [], "wer": []}
 
+    graphs = None
+    if ar.graph and world == 1:
+        ar.no_prof = True
+        p_snapshot = p.clone()
+        graphs = [stepper.capture(p, cleans[j], labels[j], logits_out=logits_buf[j]) for j in range(NB)]
+        p.copy_(p_snapshot)                      # capture ran the step for real: restore the starting point
+
     def launch(i):
         k = i % 2
-        r = stepper.step(p, cleans[i % NB], labels[i % NB], want_logits=True, logits_out=logits_buf[k])
+        if graphs is not None:
+            graphs[i % NB][0].replay()
+            r = graphs[i % NB][1]
+        else:
+            r = stepper.step(p, cleans[i % NB], labels[i % NB], want_logits=True, logits_out=logits_buf[k])
         ids_host[k].copy_(torch.argmax(r["logits"], dim=-1).to(torch.int16), non_blocking=True)
         loss_host[k].copy_(r["loss"].reshape(1), non_blocking=True)
         done[k].record()
@@ -206,7 +218,7 @@ def main():
         fl_step = 2.0 * a.fwd_flops_per_clip(L) * B
         res = {
             "metric": "pgd_steps_per_sec", "value": round(world * ar.steps / dt, 4),
-            "unit": "steps/s (one step = PGD step on 32 x 10 s clips; counted over all ranks)",
+            "unit": f"steps/s (one step = PGD step on {B} x {ar.seconds:g} s clips; counted over all ranks)",
             "n_gpus": world, "steps": ar.steps, "warmup": ar.warmup, "ms_per_step": round(1e3 * dt / ar.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if ar.dtype == "bf16" else "bf16x3 (split-bf16, fp32-parity)", "data": "synthetic",
@@ -215,7 +227,7 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "samples_per_clip": L, "parallelism": f"dp{world}",
                        "model_tflop_per_step_per_gpu": round(fl_step / 1e12, 3),
                        "model_tflops_achieved_per_gpu": round(fl_step / (dt / ar.steps) / 1e12, 2),
-                       "last_loss": bookkeeping["loss"][-1], "last_wer": bookkeeping["wer"][-1]},
+                       "hip_graph": bool(graphs), "last_loss": bookkeeping["loss"][-1], "last_wer": bookkeeping["wer"][-1]},
             "roofline": roofline,
         }
         if not ar.no_cpu_baseline and world == 1:

@@ -69,3 +69,22 @@ class PgdStepper:
                     _lib.check(lib.paa_project(self.proj.h, prm, _lib.ptr(p), 1, _lib.ptr(clean), B, L, st))
         r["loss"] = self.stats[0]
         return r
+
+    def capture(self, p, clean, labels, logits_out=None):
+        """Capture one step on fixed buffers into a hipGraph (the launch sequence allocates nothing and never
+        synchronises, so it is capturable as is).  Returns (graph, result dict); ``graph.replay()`` re-runs the step
+        in place on ``p`` with whatever ``clean`` / ``labels`` currently hold.  Single-rank only."""
+        if self.world > 1:
+            raise RuntimeError("graph capture of the data-parallel step is not enabled")
+        lab = labels.to(device=self.dev, dtype=torch.int32).contiguous()
+        if logits_out is None:
+            logits_out = torch.empty(clean.shape[0], self.model.frames, self.model.arch.vocab_size, device=self.dev)
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):                       # warm-up on the side stream, as torch's capture rules require
+            self.step(p, clean, lab, logits_out=logits_out)
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            r = self.step(p, clean, lab, logits_out=logits_out)
+        return g, r
