@@ -156,6 +156,8 @@ def test_gemm_bf16_operands(prec):
     Cc, k, s, M = 32, 3, 2, 250
     _bf_case("convview", dict(M=M, N=Cc, K=k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Cc, row_period=50, row_valid=49, act=1),
              dict(A=(s * M + 8) * Cc, B=Cc * k * Cc, C=M * Cc, C_pre=M * Cc), prec)
+    _bf_case("tallM", dict(M=2500, N=200, K=320, lda=320, ldb=320, ldc=200, act=1), dict(A=2500 * 320, B=200 * 320, C=2500 * 200, bias=200, C_pre=2500 * 200), prec)
+    _bf_case("tallM_k64", dict(M=2304, N=384, K=64, lda=64, ldb=64, ldc=384), dict(A=2304 * 64, B=384 * 64, C=2304 * 384), prec)
     _bf_case("n32k40", dict(M=200, N=32, K=40, lda=40, ldb=40, ldc=32), dict(A=200 * 40, B=32 * 40, C=200 * 32, bias=32), prec)
     B, G, Hg, Kt, T, P = 2, 4, 16, 16, 40, 41
     H = G * Hg
