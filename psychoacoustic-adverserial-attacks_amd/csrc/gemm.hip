@@ -10,8 +10,6 @@
 // stride — which is how the strided 1-D convolutions become plain GEMMs on a channel-last layout —
 // segmented K with a zero-filled time window (the grouped positional convolution), and the
 // M-/N-contiguous (transposed) operands of the attention backward products.
-#include <stdlib.h>
-
 #include <algorithm>
 #include <vector>
 
@@ -428,232 +426,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     epilogue<NJ, MI>(d, acc, m0 + wm * (32 * MI) + 4 * lh, n0 + wn * (BN / 2) + lr, z1, z2);
 }
 
-// ---- bf16 operands, LDS-DMA ring + phase-staggered wave groups ("ping-pong") ------------------------------------
-// For regular shapes (K % 64 == 0, no window / segmentation, bf16 mode).  256 x 128 x 64 tile, 8 waves (4 x 2, 64 x 64
-// each), ONE workgroup per CU.  Operand tiles go global -> LDS with global_load_lds_dwordx4 into a 3-stage ring (no
-// staging registers, no ds_write); bank conflicts are removed by an XOR swizzle applied to the SOURCE chunk (position
-// p = lane&7 of row r receives global chunk p ^ ((r>>1)&7)) and undone in the fragment reads.
-// Every wave alternates an R phase (ds_read the 16 fragments of a K tile) and an M phase (its 16 MFMAs), one raw
-// s_barrier after each.  Waves 4-7 execute ONE extra barrier up front, so for the whole loop they are one phase behind
-// waves 0-3: on every SIMD (which hosts wave w and wave w+4) one wave is always in its M phase while the other reads
-// LDS, and the matrix pipe never waits for a barrier or for fragment-read latency.  Timeline of barrier intervals I_n:
-//   I_2k: group 0 reads tile k, group 1 multiplies tile k-1, ALL waves issue the DMA of tile k+2 (its stage held tile
-//   k-1, whose last reader finished in I_2k-1);  I_2k+1: group 0 multiplies tile k, group 1 reads tile k, and all waves
-//   end the interval with a COUNTED s_waitcnt vmcnt for their pieces of tile k+1 (tile k+2 stays in flight).
-typedef __attribute__((address_space(1))) const void* gas_ptr;
-typedef __attribute__((address_space(3))) void* las_ptr;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void hard_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int DIAG>
-__global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs g) {
-    constexpr int BM = 256, BN = 128, WN = 2, NW = 8, MI = 2, NJ = 2, NS = 3;
-    constexpr int ROWS = BM + BN;                         // A rows then B rows
-    constexpr int GPW = ROWS / 8 / NW;                    // wave-instructions (8-row groups) per wave per K tile = 6
-    constexpr int STAGE = ROWS * 128;                     // bytes
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int orig = blockIdx.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
-    const int z1 = z / d.batch2, z2 = z - z1 * d.batch2;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(d.A) + z1 * d.a_s1 + z2 * d.a_s2;
-    const unsigned short* B = reinterpret_cast<const unsigned short*>(d.B) + z1 * d.b_s1 + z2 * d.b_s2;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                            // 0: waves 0-3, 1: waves 4-7 (one phase behind)
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    const unsigned short* src[GPW];
-#pragma unroll
-    for (int i = 0; i < GPW; ++i) {
-        const int r = (i * NW + wave) * 8 + (lane >> 3);  // tile row: [0, BM) A, [BM, BM+BN) B
-        const int c = (lane & 7) ^ ((r >> 1) & 7);        // global chunk that lands at position lane&7
-        src[i] = (r < BM) ? A + (int64_t)min(m0 + r, d.M - 1) * d.lda + c * 8
-                          : B + (int64_t)min(n0 + r - BM, d.N - 1) * d.ldb + c * 8;
-    }
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = d.K / 64;
-#define PAA_ISSUE(KT)                                                                                        \
-    if ((KT) < nk && (DIAG < 2 || (KT) < 3)) {                                                                                         \
-        unsigned char* stage_ = smem + ((KT) % NS) * STAGE;                                                  \
-        _Pragma("unroll") for (int i = 0; i < GPW; ++i)                                                      \
-            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)(KT) * 64),                         \
-                                             (las_ptr)(stage_ + (i * NW + wave) * 1024), 16, 0, 0);           \
-    }
-#define PAA_WAIT_NEXT(KT) /* own pieces of tile KT+1 landed; tile KT+2 (if any) may stay in flight */        \
-    if (DIAG < 2 && (KT) + 1 < nk) { if ((KT) + 2 < nk) wait_vmcnt<GPW>(); else wait_vmcnt<0>(); }
-
-    PAA_ISSUE(0);
-    PAA_ISSUE(1);
-    if (nk > 1) wait_vmcnt<GPW>(); else wait_vmcnt<0>();      // tile 0
-    hard_barrier();                                           // B_0
-    if (grp == 1) { PAA_ISSUE(2); if (DIAG < 3) hard_barrier(); }           // interval I_0 of the late group
-    for (int kt = 0; kt < nk; ++kt) {
-        // ---- R phase: fragments of tile kt ------------------------------------------------------------------
-        if (grp == 0) PAA_ISSUE(kt + 2);
-        const unsigned char* sA = smem + (kt % NS) * STAGE;
-        const unsigned char* sB = sA + BM * 128;
-        bf16x8 af[4][MI], bfr[4][NJ];
-        if (DIAG == 0 || kt == 0)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = wm * 64 + i * 32 + lr;
-                af[ks][i] = *reinterpret_cast<const bf16x8*>(sA + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int r = wn * 64 + j * 32 + lr;
-                bfr[ks][j] = *reinterpret_cast<const bf16x8*>(sB + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
-            }
-        }
-        if (grp == 1) PAA_WAIT_NEXT(kt);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // fragments are in registers before the phase ends
-        if (DIAG < 3) hard_barrier();
-        // ---- M phase ------------------------------------------------------------------------------------------
-        if (grp == 1) PAA_ISSUE(kt + 3);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) PAA_WAIT_NEXT(kt);
-        if (DIAG < 3 && !(grp == 1 && kt == nk - 1)) hard_barrier();
-    }
-#undef PAA_ISSUE
-#undef PAA_WAIT_NEXT
-    epilogue<NJ, MI>(d, acc, m0 + wm * 64 + 4 * lh, n0 + wn * 64 + lr, z1, z2);
-}
-
-// ---- 256 x 256 x 32 variant of the ping-pong kernel: half the L2 -> LDS bytes per FLOP of the 256 x 128 tile ------------
-// 8 waves as 2 (M) x 4 (N), 128 x 64 per wave (8 accumulators); K tiles of 32 (rows of 64 B, 4 chunks; one DMA
-// wave-instruction = 16 rows), 4-stage ring (4 x 32 KB), two tiles in flight behind the counted wait.  Source swizzle
-// for 64-byte rows: position p = lane&3 of row r receives chunk p ^ ((r>>2)&3).
-__global__ __launch_bounds__(512) void k_gemm_pp2(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, WN = 4, NW = 8, MI = 4, NJ = 2, NS = 4;
-    constexpr int ROWS = BM + BN;
-    constexpr int GPW = ROWS / 16 / NW;                   // 16-row groups per wave per K tile = 4
-    constexpr int STAGE = ROWS * 64;                      // bytes
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int orig = blockIdx.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
-    const int z1 = z / d.batch2, z2 = z - z1 * d.batch2;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(d.A) + z1 * d.a_s1 + z2 * d.a_s2;
-    const unsigned short* B = reinterpret_cast<const unsigned short*>(d.B) + z1 * d.b_s1 + z2 * d.b_s2;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    const unsigned short* src[GPW];
-#pragma unroll
-    for (int i = 0; i < GPW; ++i) {
-        const int r = (i * NW + wave) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        src[i] = (r < BM) ? A + (int64_t)min(m0 + r, d.M - 1) * d.lda + c * 8
-                          : B + (int64_t)min(n0 + r - BM, d.N - 1) * d.ldb + c * 8;
-    }
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = d.K / 32;
-#define PAA_ISSUE(KT)                                                                                        \
-    if ((KT) < nk) {                                                                                         \
-        unsigned char* stage_ = smem + ((KT) % NS) * STAGE;                                                  \
-        _Pragma("unroll") for (int i = 0; i < GPW; ++i)                                                      \
-            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)(KT) * 32),                         \
-                                             (las_ptr)(stage_ + (i * NW + wave) * 1024), 16, 0, 0);           \
-    }
-#define PAA_WAIT_NEXT(KT) /* own pieces of tile KT+1 landed; tiles KT+2, KT+3 (if any) may stay in flight */ \
-    if ((KT) + 1 < nk) {                                                                                     \
-        if ((KT) + 3 < nk) wait_vmcnt<2 * GPW>(); else if ((KT) + 2 < nk) wait_vmcnt<GPW>(); else wait_vmcnt<0>(); \
-    }
-
-    PAA_ISSUE(0);
-    PAA_ISSUE(1);
-    PAA_ISSUE(2);
-    if (nk > 2) wait_vmcnt<2 * GPW>(); else if (nk > 1) wait_vmcnt<GPW>(); else wait_vmcnt<0>();      // tile 0
-    hard_barrier();                                           // B_0
-    if (grp == 1) { PAA_ISSUE(3); hard_barrier(); }
-    for (int kt = 0; kt < nk; ++kt) {
-        if (grp == 0) PAA_ISSUE(kt + 3);
-        const unsigned char* sA = smem + (kt % NS) * STAGE;
-        const unsigned char* sB = sA + BM * 64;
-        bf16x8 af[2][MI], bfr[2][NJ];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = wm * 128 + i * 32 + lr;
-                af[ks][i] = *reinterpret_cast<const bf16x8*>(sA + r * 64 + (((2 * ks + lh) ^ ((r >> 2) & 3)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int r = wn * 64 + j * 32 + lr;
-                bfr[ks][j] = *reinterpret_cast<const bf16x8*>(sB + r * 64 + (((2 * ks + lh) ^ ((r >> 2) & 3)) << 4));
-            }
-        }
-        if (grp == 1) PAA_WAIT_NEXT(kt);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        hard_barrier();
-        if (grp == 1) PAA_ISSUE(kt + 4);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) PAA_WAIT_NEXT(kt);
-        if (!(grp == 1 && kt == nk - 1)) hard_barrier();
-    }
-#undef PAA_ISSUE
-#undef PAA_WAIT_NEXT
-    // two MI = 2 passes keep the epilogue's register footprint small
-    epilogue<NJ, 2>(d, reinterpret_cast<f32x16(&)[2][NJ]>(acc[0]), m0 + wm * 128 + 4 * lh, n0 + wn * 64 + lr, z1, z2);
-    epilogue<NJ, 2>(d, reinterpret_cast<f32x16(&)[2][NJ]>(acc[2]), m0 + wm * 128 + 64 + 4 * lh, n0 + wn * 64 + lr, z1, z2);
-}
-
 template <int BN, int PREC>
 static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
     const bool akc = g.d.a_kcontig != 0, bkc = g.d.b_kcontig != 0;
@@ -697,11 +469,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     // 256 x 128 tile (8 waves, 2 workgroups per CU) for every large-M product; 128 x 128 (4 waves) was 4-8 % faster on
     // the isolated M = 16000, N <= 2304 shapes but made no difference inside the step (A/B on one device)
     const bool tall = d.operand_bf16 && !narrow && d.M >= 2048;
-    static const int pp_mode = getenv("PAA_GEMM_PP") ? atoi(getenv("PAA_GEMM_PP")) : 0;      // measurement knob
-    const bool pp = pp_mode && tall && !d.precision && !d.a_kseg && !d.a_window && (d.K % 64) == 0 && d.K >= 192;
-    const bool pp2 = pp && pp_mode == 2 && (d.K % 32) == 0;
     g.tiles_m = cdiv(d.M, tall ? 256 : G_BM);
-    g.tiles_n = cdiv(d.N, pp2 ? 256 : bn);
+    g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
     if (prof) {
@@ -709,14 +478,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         g_prof.flops[g_prof.n] = 2.0 * d.M * d.N * (double)d.K * d.batch;
         g_prof.variant[g_prof.n] = (tall ? 32 : 0) + (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     }
-    if (pp2) hipLaunchKernelGGL(k_gemm_pp2, grid, dim3(512), 0, st, g);
-    else if (pp) {
-        if (pp_mode == 11) hipLaunchKernelGGL(k_gemm_pp<1>, grid, dim3(512), 0, st, g);
-        else if (pp_mode == 12) hipLaunchKernelGGL(k_gemm_pp<2>, grid, dim3(512), 0, st, g);
-        else if (pp_mode == 13) hipLaunchKernelGGL(k_gemm_pp<3>, grid, dim3(512), 0, st, g);
-        else hipLaunchKernelGGL(k_gemm_pp<0>, grid, dim3(512), 0, st, g);
-    }
-    else if (d.operand_bf16) {
+    if (d.operand_bf16) {
         if (narrow) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 64, 1, 2>), grid, dim3(256), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 64, 0, 2>), grid, dim3(256), 0, st, g); }
         else if (tall) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<256, 128, 1, 4>), grid, dim3(512), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<256, 128, 0, 4>), grid, dim3(512), 0, st, g); }
         else { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 128, 1, 2>), grid, dim3(256), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 128, 0, 2>), grid, dim3(256), 0, st, g); }
