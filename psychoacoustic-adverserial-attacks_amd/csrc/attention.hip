@@ -9,8 +9,9 @@
 // accumulator rows: with v_mfma_f32_32x32x16_bf16 the score tile X[other][own] has its rows in the 16
 // accumulator registers (row = (e&3) + 8(e>>2) + 4(lane>>5)) and its columns on the lanes.  Products that
 // then sum over `other` take bf16(X) straight from the accumulator registers as their B operand (k order
-// inside a 16-deep step: 16s + 8(j>>2) + 4h + (j&3), so the A operand is read from a TRANSPOSED LDS image
-// [d][other] with two 8-byte reads per step).  Every statistic of an own position (running max / sum, lse,
+// inside a 16-deep step: 16s + 8(j>>2) + 4h + (j&3); the matching A operand — 4 consecutive `other` rows of one d
+// column — comes out of the ROW-MAJOR LDS tile through gfx950's transposing read ds_read_b64_tr_b16, two per step,
+// so no transposed copy of any tile is ever staged).  Every statistic of an own position (running max / sum, lse,
 // delta) lives in its two lanes (lane, lane^32): no LDS reductions.
 //   forward, dQ : own = queries, other = keys          dK/dV : own = keys, other = queries
 // Q/K/V/dO are rows of the (M, 3H) / (M, H) bf16 planes the GEMM epilogues write; outputs go back as bf16.
@@ -24,37 +25,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int AT_D = 64;            // head dim
 constexpr int AT_RM = 72;           // row-major tile row stride (bf16): 144 B, conflict-free ds_read_b128
-constexpr int AT_TR = 36;           // transposed tile row stride (bf16): 72 B, conflict-free ds_read_b64
 
-// stage a 32 x 64 tile (rows r0.., valid while < rlim) of a bf16 matrix with row stride ld:
-//   rm: row-major [32][AT_RM] (optional)    tr: transposed [64][AT_TR] (optional)
+// stage a 32 x 64 tile (rows r0.., valid while < rlim, zero beyond) of a bf16 matrix with row stride ld into a
+// row-major LDS tile [32][AT_RM]; 256 threads, one 16-byte chunk each
 __device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ src, int64_t ld, int r0, int rlim,
-                                           unsigned short* rm, unsigned short* tr) {
+                                           unsigned short* rm) {
     const int tid = threadIdx.x;
     const int row = tid >> 3, ch = tid & 7;
     uint4 x = make_uint4(0u, 0u, 0u, 0u);
     if (r0 + row < rlim) x = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + row) * ld + ch * 8);
-    if (rm) *reinterpret_cast<uint4*>(rm + row * AT_RM + ch * 8) = x;
-    if (tr) {
-        const unsigned w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tr[(ch * 8 + 2 * j) * AT_TR + row] = (unsigned short)(w[j] & 0xffffu);
-            tr[(ch * 8 + 2 * j + 1) * AT_TR + row] = (unsigned short)(w[j] >> 16);
-        }
-    }
+    *reinterpret_cast<uint4*>(rm + row * AT_RM + ch * 8) = x;
 }
 
 // A fragment of k-step s from a row-major tile: lane (lr, lh) -> row lr, elements 16s + 8lh .. +7
 __device__ __forceinline__ bf16x8 frag_rm(const unsigned short* rm, int lr, int lh, int s) {
     return *reinterpret_cast<const bf16x8*>(rm + lr * AT_RM + 16 * s + 8 * lh);
 }
-// A fragment of k-step s2 from a transposed tile, in the accumulator's k order: row (dt*32 + lr),
-// elements j<4: 16 s2 + 4 lh + j ; j>=4: 16 s2 + 8 + 4 lh + (j-4)
-__device__ __forceinline__ bf16x8 frag_tr(const unsigned short* tr, int lr, int lh, int dt, int s2) {
-    const unsigned short* p = tr + (dt * 32 + lr) * AT_TR + 16 * s2 + 4 * lh;
-    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
-    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 8);
+// A fragment of the TRANSPOSED tile for k-step s2, in the accumulator's k order, read from the row-major tile:
+// lane (lr, lh) gets column d = dt*32 + lr of rows 16 s2 + 4 lh + (0..3) [elements 0-3] and +8 [elements 4-7].
+// ds_read_b64_tr_b16: within a group of 16 lanes, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4 x 16 block, and lane i receives column i of the 4 rows (probed on the device: tools/scratch/tr_test.hip).
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned short* rm, int lr, int lh, int dt, int s2) {
+    const int i = lr & 15;
+    const unsigned short* p = rm + (16 * s2 + 4 * lh + (i >> 2)) * AT_RM + dt * 32 + (lr & 16) + 4 * (i & 3);
+    typedef __attribute__((address_space(3))) bf16x4* lds4;
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + 8 * AT_RM));
     bf16x8 r;
     r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
     return r;
@@ -88,7 +84,7 @@ __device__ __forceinline__ void store_own(unsigned short* __restrict__ dst, int6
 // ------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sK[32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sVt[64 * AT_TR];
+    __shared__ __attribute__((aligned(16))) unsigned short sV[32 * AT_RM];
     const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int q = blockIdx.x * 128 + wave * 32 + lr;
@@ -104,8 +100,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
     const int nt = (a.T + 31) / 32;
     for (int kt = 0; kt < nt; ++kt) {
-        stage_tile(base + a.H, ld, kt * 32, a.T, sK, nullptr);
-        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, nullptr, sVt);
+        stage_tile(base + a.H, ld, kt * 32, a.T, sK);
+        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, sV);
         __syncthreads();
         f32x16 s;
 #pragma unroll
@@ -135,7 +131,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 pb = pack8(p, s2);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sVt, lr, lh, dt, s2), pb, o[dt], 0, 0, 0);
+            for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sV, lr, lh, dt, s2), pb, o[dt], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -149,7 +145,6 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 // own = queries.  Also computes delta = rowsum(dO * O) and stores it for the dK/dV kernel.
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sK[32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sKt[64 * AT_TR];
     __shared__ __attribute__((aligned(16))) unsigned short sV[32 * AT_RM];
     const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
@@ -177,8 +172,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
     for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
     const int nt = (a.T + 31) / 32;
     for (int kt = 0; kt < nt; ++kt) {
-        stage_tile(base + a.H, ld, kt * 32, a.T, sK, sKt);
-        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, sV, nullptr);
+        stage_tile(base + a.H, ld, kt * 32, a.T, sK);
+        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, sV);
         __syncthreads();
         f32x16 s, dp;
 #pragma unroll
@@ -199,7 +194,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 db = pack8(ds, s2);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sKt, lr, lh, dt, s2), db, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sK, lr, lh, dt, s2), db, dq[dt], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -210,9 +205,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
 // own = keys (lanes), other = queries (accumulator rows).
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sQ[32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sQt[64 * AT_TR];
     __shared__ __attribute__((aligned(16))) unsigned short sdO[32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sdOt[64 * AT_TR];
     __shared__ float sLse[32], sDel[32];
     const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
@@ -230,8 +223,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
     for (int e = 0; e < 16; ++e) { dk[0][e] = 0.f; dk[1][e] = 0.f; dv[0][e] = 0.f; dv[1][e] = 0.f; }
     const int nt = (a.T + 31) / 32;
     for (int qt = 0; qt < nt; ++qt) {
-        stage_tile(base, ld, qt * 32, a.T, sQ, sQt);
-        stage_tile(dob, a.H, qt * 32, a.T, sdO, sdOt);
+        stage_tile(base, ld, qt * 32, a.T, sQ);
+        stage_tile(dob, a.H, qt * 32, a.T, sdO);
         if (threadIdx.x < 32) {
             const int qq = qt * 32 + threadIdx.x;
             sLse[threadIdx.x] = qq < a.T ? a.lse[(int64_t)bh * a.Tp + qq] : INFINITY;     // exp2(-inf) = 0 for pad queries
@@ -258,8 +251,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
             const bf16x8 pb = pack8(p, s2), db = pack8(ds, s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sdOt, lr, lh, dt, s2), pb, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sQt, lr, lh, dt, s2), db, dk[dt], 0, 0, 0);
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sdO, lr, lh, dt, s2), pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sQ, lr, lh, dt, s2), db, dk[dt], 0, 0, 0);
             }
         }
         __syncthreads();
