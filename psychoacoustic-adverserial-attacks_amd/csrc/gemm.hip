@@ -10,6 +10,7 @@
 // stride — which is how the strided 1-D convolutions become plain GEMMs on a channel-last layout —
 // segmented K with a zero-filled time window (the grouped positional convolution), and the
 // M-/N-contiguous (transposed) operands of the attention backward products.
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 
@@ -289,16 +290,160 @@ __global__ __launch_bounds__(G_NT) void k_gemm(GemmArgs g) {
     epilogue<NJ, 2>(d, acc, m0 + wm * 64 + 4 * lh, n0 + wn * (BN / 2) + lr, z1, z2);
 }
 
+// ---- vector epilogue of the bf16-operand kernel ------------------------------------------------------
+// An accumulator leaves the MFMA with one COLUMN per lane (4 consecutive rows in 4 registers).  A 4 x 4 transpose
+// inside each lane quad (two DPP quad_perm rounds, no LDS) turns that into one ROW per lane with 4 consecutive
+// columns in 4 registers; together with the column interleave of the B tile (see store_bf) a lane then owns 8
+// consecutive columns of its row: results leave as 16-byte vectors (2 x float4 f32, 1 x uint4 bf16: a wave store
+// covers 8 rows x 256 B / 128 B, whole cache lines), and aux / residual / bias arrive the same way, loaded one
+// row group ahead of their use.  Needs N, ldc, ld_aux, ld_res and the batch strides to be multiples of 8.
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+}
+// in: lane b of the quad holds M[k][b] in x_k; out: lane b holds M[b][k] in x_k
+__device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, float& x3, bool o1, bool o2) {
+    float s = dpp_quad_xor1(o1 ? x0 : x1);
+    float t = dpp_quad_xor1(o1 ? x2 : x3);
+    if (o1) { x0 = s; x2 = t; } else { x1 = s; x3 = t; }
+    s = dpp_quad_xor2(o2 ? x0 : x2);
+    t = dpp_quad_xor2(o2 ? x1 : x3);
+    if (o2) { x0 = s; x1 = t; } else { x2 = s; x3 = t; }
+}
+
+// `ex` is the one extra f32 operand stream of the epilogue: aux (GELU_GRAD) or the residual — the host takes the
+// scalar epilogue when a product asks for both.  All per-lane addresses are 32-bit element offsets from uniform bases.
+template <int MI, bool FAST>
+__device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&acc)[MI][2], int m0w, int n0w, int z1, int z2, int lane) {
+    const int lr = lane & 31, lh = lane >> 5, qa = lr >> 2, qb = lr & 3;
+    const bool o1 = qb & 1, o2 = qb & 2;
+    const int col = n0w + 8 * qa;                       // this lane's 8 columns
+    const int row0 = m0w + 4 * lh + qb;                 // + 32 i + 8 g
+    const bool col_ok = col < d.N;
+    const int act = d.act;
+    const bool gg = act == PAA_ACT_GELU_GRAD;
+    const int64_t cbase = z1 * d.c_s1 + z2 * d.c_s2;
+    float* __restrict__ C = d.C ? d.C + cbase : nullptr;
+    float* __restrict__ Cp = d.C_pre ? d.C_pre + cbase : nullptr;
+    unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + cbase : nullptr;
+    unsigned short* __restrict__ Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + cbase : nullptr;
+    const float* __restrict__ ex = gg ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2
+                                      : (d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr);
+    const unsigned ldc = (unsigned)d.ldc, ldx = (unsigned)(gg ? d.ld_aux : d.ld_res);
+    const unsigned co = (unsigned)row0 * ldc + (unsigned)col;
+    const unsigned xo = (unsigned)row0 * ldx + (unsigned)col;
+    float bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv[k] = 0.f;
+    if (d.bias && col_ok) {
+        const float* bp = d.bias + z2 * d.bias_s2;
+        const float4 b0 = *reinterpret_cast<const float4*>(bp + (unsigned)col);
+        const float4 b1 = *reinterpret_cast<const float4*>(bp + (unsigned)col + 4u);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    const int period = d.row_period;
+    const int mrem0 = period > 0 ? row0 % period : 0;
+    const float alpha = d.alpha;
+    const bool accum = d.accumulate != 0;
+    constexpr int NG = 4 * MI;                           // row groups of 8 rows: (i, g)
+    float4 xv[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { xv[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); xv[u][1] = xv[u][0]; }
+    auto fetch = [&](int grp, float4 (&v2)[2]) {
+        const int dm = (grp >> 2) * 32 + (grp & 3) * 8;
+        if (ex && col_ok && row0 + dm < d.M) {
+            const unsigned o = xo + (unsigned)dm * ldx;
+            v2[0] = *reinterpret_cast<const float4*>(ex + o);
+            v2[1] = *reinterpret_cast<const float4*>(ex + o + 4u);
+        }
+    };
+    fetch(0, xv[0]);
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+        const int i = grp >> 2, gq = grp & 3, u = grp & 1;
+        if (grp + 1 < NG) fetch(grp + 1, xv[u ^ 1]);
+        const int dm = i * 32 + gq * 8;
+        const bool live = col_ok && row0 + dm < d.M;
+        bool dead = false;
+        if (period > 0) {
+            int rem = mrem0 + dm;
+            if (rem >= period) rem = (period >= 256) ? rem - period : rem % period;
+            dead = rem >= d.row_valid;
+        }
+        const unsigned ci = co + (unsigned)dm * ldc;
+        unsigned hp[4], lp[4];                               // packed bf16 pairs of the 8 columns
+        // the two 4-column halves go through the math one after the other: with the tile's 64 accumulator registers
+        // still live there is no room for eight interleaved GELU chains
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float x[4] = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+            quad_transpose(x[0], x[1], x[2], x[3], o1, o2);   // every lane takes part, whatever its bounds
+            const float e4[4] = {xv[u][j].x, xv[u][j].y, xv[u][j].z, xv[u][j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = x[k] * alpha + bv[4 * j + k];
+            if (act == PAA_ACT_GELU) {
+                if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(x[0], x[1], x[2], x[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = FAST ? gelu_fast(x[k]) : gelu_f(x[k]);
+                if (ex) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] += e4[k];
+                }
+            } else if (gg) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] *= FAST ? gelu_grad_fast(e4[k]) : gelu_grad_f(e4[k]);
+            } else if (ex) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] += e4[k];
+            }
+            if (dead) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = 0.f;
+            }
+            if (C && live) {
+                if (accum) {
+                    const float4 c0 = *reinterpret_cast<const float4*>(C + ci + 4u * j);
+                    x[0] += c0.x; x[1] += c0.y; x[2] += c0.z; x[3] += c0.w;
+                }
+                *reinterpret_cast<float4*>(C + ci + 4u * j) = make_float4(x[0], x[1], x[2], x[3]);
+            }
+            if (Cb) {
+                unsigned h[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = bf16_bits(x[k]);
+                hp[2 * j] = h[0] | (h[1] << 16); hp[2 * j + 1] = h[2] | (h[3] << 16);
+                if (Cbl) {
+                    unsigned l[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) l[k] = bf16_bits(x[k] - __uint_as_float(h[k] << 16));
+                    lp[2 * j] = l[0] | (l[1] << 16); lp[2 * j + 1] = l[2] | (l[3] << 16);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (Cb && live) {
+            *reinterpret_cast<uint4*>(Cb + ci) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+            if (Cbl) *reinterpret_cast<uint4*>(Cbl + ci) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+        }
+    }
+}
+
 // ---- bf16-operand main loop ------------------------------------------------------------------------
-// Both operands K-contiguous bf16 planes.  Tile 128 x BN x 64; a thread moves 16-byte chunks (8 bf16) global ->
+// Both operands K-contiguous bf16 planes.  Tile BM x BN x 64; a thread moves 16-byte chunks (8 bf16) global ->
 // registers -> LDS (ds_write_b128) with no conversion work, rows padded to 72 bf16 (144 B: the four
-// ds_read_b128 lane groups hit 16 distinct 16-byte slots).  16 (BN=128) MFMAs per wave per K tile.
+// ds_read_b128 lane groups hit 16 distinct 16-byte slots).
+// The kernel is persistent: the grid is one wave of resident workgroups and each walks tiles t, t + grid, ...;
+// the first K tile of the NEXT output tile is loaded under the last MFMA block of the current one and stored to
+// LDS before the epilogue, so neither the load latency at the head of a tile nor the epilogue's memory traffic
+// leaves the matrix pipes idle on the short-K (K = 768) products of the encoder.
 constexpr int H_BK = 64, H_LD = 72;
 
+// General loader (SEG kernels): segmented K and the zero-filled time window of the grouped positional convolution.
 template <int ROWS, bool IS_A, int NT>
 __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned short* __restrict__ base, int64_t ld,
-                                        int r0, int k0, int rlim, uint4 (&v)[ROWS * 8 / NT]) {
-    const int tid = threadIdx.x;
+                                        int r0, int k0, int rlim, uint4 (&v)[ROWS * 8 / NT], int tid) {
     const int k = k0 + ((tid & 7) << 3);
     int64_t koff = k;
     int js = 0, kc = k;
@@ -325,21 +470,46 @@ __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned s
     }
 }
 
+// Plain K-contiguous rows through a buffer resource that starts at the tile's first row and ends with the operand:
+// one 32-bit per-lane byte offset for the whole product, everything else scalar; rows past the operand's end
+// (last M / N tile) read zeros from the hardware bounds check instead of branching.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const unsigned short* base, int64_t elems) {
+    const int64_t bytes = elems > 0 ? 2 * elems : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base), 0,
+                                             (int)(unsigned)(bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes), 0x00020000);
+}
 template <int ROWS, int NT>
-__device__ __forceinline__ void store_bf(unsigned short* lds, const uint4 (&v)[ROWS * 8 / NT]) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned k0_bytes, unsigned step_bytes,
+                                         bool kok, uint4 (&v)[ROWS * 8 / NT]) {
 #pragma unroll
-    for (int i = 0; i < ROWS * 8 / NT; ++i)
-        *reinterpret_cast<uint4*>(lds + ((tid >> 3) + (NT / 8) * i) * H_LD + ((tid & 7) << 3)) = v[i];
+    for (int i = 0; i < ROWS * 8 / NT; ++i) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k0_bytes + i * step_bytes, 0);
+        v[i] = kok ? make_uint4(x.x, x.y, x.z, x.w) : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// PERM (B tile of the vector-epilogue kernels): tile row n of each 64-row group goes to LDS row
+// ((n >> 2) & 1) * 32 + (n >> 3) * 4 + (n & 3), so that lane lr of accumulator j multiplies column
+// 8 (lr >> 2) + 4 j + (lr & 3): after the quad transpose a lane owns 8 consecutive columns.
+template <int ROWS, int NT, bool PERM>
+__device__ __forceinline__ void store_bf(unsigned short* lds, const uint4 (&v)[ROWS * 8 / NT], int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / NT; ++i) {
+        int r = (tid >> 3) + (NT / 8) * i;
+        if (PERM) r = (r & ~63) | ((((r >> 2) & 1) << 5) + (((r & 63) >> 3) << 2) + (r & 3));
+        *reinterpret_cast<uint4*>(lds + r * H_LD + ((tid & 7) << 3)) = v[i];
+    }
 }
 
 // WM x 2 waves; each wave owns a (BM / WM) x (BN / 2) sub-tile = MI x NJ accumulators of 32 x 32.
-template <int BM, int BN, int PREC, int WM>
+template <int BM, int BN, int PREC, int WM, bool VEC, bool SEG>
 __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_gemm_bf(GemmArgs g) {
     constexpr int NT = WM * 128;
     constexpr int NPL = PREC ? 2 : 1;
     constexpr int NJ = BN / 64;
     constexpr int MI = BM / (32 * WM);
+    static_assert(!VEC || NJ == 2, "vector epilogue needs 64 columns per wave");
     __shared__ __attribute__((aligned(16))) unsigned short smem[NPL * (BM + BN) * H_LD];
     unsigned short* sAh = smem;
     unsigned short* sAl = smem + (PREC ? BM * H_LD : 0);
@@ -348,82 +518,140 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
 
     const paa_gemm_desc& d = g.d;
     const int nwg = g.tiles_m * g.tiles_n;
-    const int orig = blockIdx.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
-    const int z1 = z / d.batch2, z2 = z - z1 * d.batch2;
-    const int64_t aoff = z1 * d.a_s1 + z2 * d.a_s2, boff = z1 * d.b_s1 + z2 * d.b_s2;
-    const unsigned short* Ah = reinterpret_cast<const unsigned short*>(d.A) + aoff;
-    const unsigned short* Bh = reinterpret_cast<const unsigned short*>(d.B) + boff;
-    const unsigned short* Al = PREC ? reinterpret_cast<const unsigned short*>(d.A_lo) + aoff : nullptr;
-    const unsigned short* Bl = PREC ? reinterpret_cast<const unsigned short*>(d.B_lo) + boff : nullptr;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    uint4 rah[BM * 8 / NT], rbh[BN * 8 / NT], ral[PREC ? BM * 8 / NT : 1], rbl[PREC ? BN * 8 / NT : 1];
+    const int total = nwg * d.batch;
     const int nk = (d.K + H_BK - 1) / H_BK;
-    load_bf<BM, true, NT>(d, Ah, d.lda, m0, 0, d.M, rah);
-    load_bf<BN, false, NT>(d, Bh, d.ldb, n0, 0, d.N, rbh);
-    if constexpr (PREC) {
-        load_bf<BM, true, NT>(d, Al, d.lda, m0, 0, d.M, ral);
-        load_bf<BN, false, NT>(d, Bl, d.ldb, n0, 0, d.N, rbl);
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        store_bf<BM, NT>(sAh, rah);
-        store_bf<BN, NT>(sBh, rbh);
-        if constexpr (PREC) { store_bf<BM, NT>(sAl, ral); store_bf<BN, NT>(sBl, rbl); }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            const int k0 = (kt + 1) * H_BK;
-            load_bf<BM, true, NT>(d, Ah, d.lda, m0, k0, d.M, rah);
-            load_bf<BN, false, NT>(d, Bh, d.ldb, n0, k0, d.N, rbh);
+
+    // tile t -> (batch z, row m0, column n0).  XCD-aware order inside a batch entry: workgroups that share
+    // (id % 8) — one XCD's L2 — walk a contiguous run of tiles, A row-panel major (bijective for any tile count).
+    struct Tile { int m0, n0, z1, z2; };
+    auto decode = [&](int t) {
+        Tile c;
+        const int z = t / nwg, orig = t - z * nwg;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+        c.m0 = tm * BM; c.n0 = tn * BN;
+        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
+        return c;
+    };
+    uint4 rah[BM * 8 / NT], rbh[BN * 8 / NT], ral[PREC ? BM * 8 / NT : 1], rbl[PREC ? BN * 8 / NT : 1];
+    auto load_tile = [&](const Tile& c, int k0, int tid) {
+        const int64_t aoff = c.z1 * d.a_s1 + c.z2 * d.a_s2, boff = c.z1 * d.b_s1 + c.z2 * d.b_s2;
+        if constexpr (SEG) {
+            load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A) + aoff, d.lda, c.m0, k0, d.M, rah, tid);
+            load_bf<BN, false, NT>(d, reinterpret_cast<const unsigned short*>(d.B) + boff, d.ldb, c.n0, k0, d.N, rbh, tid);
             if constexpr (PREC) {
-                load_bf<BM, true, NT>(d, Al, d.lda, m0, k0, d.M, ral);
-                load_bf<BN, false, NT>(d, Bl, d.ldb, n0, k0, d.N, rbl);
+                load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A_lo) + aoff, d.lda, c.m0, k0, d.M, ral, tid);
+                load_bf<BN, false, NT>(d, reinterpret_cast<const unsigned short*>(d.B_lo) + boff, d.ldb, c.n0, k0, d.N, rbl, tid);
+            }
+        } else {
+            const int64_t a0 = aoff + (int64_t)c.m0 * d.lda, b0 = boff + (int64_t)c.n0 * d.ldb;
+            const int64_t ae = (int64_t)(d.M - 1 - c.m0) * d.lda + d.K, be = (int64_t)(d.N - 1 - c.n0) * d.ldb + d.K;
+            const unsigned kc = (unsigned)((tid & 7) << 3);
+            const unsigned va = 2u * ((unsigned)(tid >> 3) * (unsigned)d.lda + kc), vb = 2u * ((unsigned)(tid >> 3) * (unsigned)d.ldb + kc);
+            const unsigned sa = 2u * (NT / 8) * (unsigned)d.lda, sb = 2u * (NT / 8) * (unsigned)d.ldb;
+            const bool kok = k0 + (int)kc < d.K;
+            load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A) + a0, ae), va, 2u * k0, sa, kok, rah);
+            load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * k0, sb, kok, rbh);
+            if constexpr (PREC) {
+                load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A_lo) + a0, ae), va, 2u * k0, sa, kok, ral);
+                load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B_lo) + b0, be), vb, 2u * k0, sb, kok, rbl);
             }
         }
+    };
+    auto store_tile = [&](int tid) {
+        store_bf<BM, NT, false>(sAh, rah, tid);
+        store_bf<BN, NT, VEC>(sBh, rbh, tid);
+        if constexpr (PREC) { store_bf<BM, NT, false>(sAl, ral, tid); store_bf<BN, NT, VEC>(sBl, rbl, tid); }
+    };
+
+    int t = blockIdx.x;
+    if (t >= total) return;
+    Tile cur = decode(t);
+    load_tile(cur, 0, threadIdx.x);
+    store_tile(threadIdx.x);
+    for (;;) {
+        // The thread index is made opaque once per tile: everything derived from it (global / LDS addresses, lane
+        // coordinates) is then recomputed per tile instead of being kept alive — and spilled — across the epilogue.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+        const int lr = lane & 31, lh = lane >> 5;
+        const int tnx = t + gridDim.x;
+        const bool more = tnx < total;
+        const Tile nxt = more ? decode(tnx) : cur;
+        f32x16 acc[MI][NJ];
 #pragma unroll
-        for (int ks = 0; ks < H_BK / 16; ++ks) {
-            bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int off = (wm * (32 * MI) + i * 32 + lr) * H_LD + ks * 16 + lh * 8;
-                ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
-                if (PREC) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
-            }
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int off = (wn * (BN / 2) + j * 32 + lr) * H_LD + ks * 16 + lh * 8;
-                bh[j] = *reinterpret_cast<const bf16x8*>(sBh + off);
-                if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sBl + off);
-            }
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();                                   // K tile kt is in LDS
+            const bool last = kt + 1 == nk;
+            if (!last) load_tile(cur, (kt + 1) * H_BK, tid);
+            else if (more) load_tile(nxt, 0, tid);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int ks = 0; ks < H_BK / 16; ++ks) {
+                bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int off = (wm * (32 * MI) + i * 32 + lr) * H_LD + ks * 16 + lh * 8;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
+                    if (PREC) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    if (PREC) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    const int off = (wn * (BN / 2) + j * 32 + lr) * H_LD + ks * 16 + lh * 8;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(sBh + off);
+                    if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sBl + off);
                 }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (PREC) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                                   // every wave is done with K tile kt
+            if (!last || more) store_tile(tid);
         }
-        __syncthreads();
+        {
+            int te = tid;
+            asm volatile("" : "+v"(te));
+            const int el = te & 63, ew = te >> 6;
+            if constexpr (VEC) epilogue_vec<MI, PREC == 0>(d, acc, cur.m0 + (ew >> 1) * (32 * MI), cur.n0 + (ew & 1) * (BN / 2), cur.z1, cur.z2, el);
+            else epilogue<NJ, MI>(d, acc, cur.m0 + (ew >> 1) * (32 * MI) + 4 * (el >> 5), cur.n0 + (ew & 1) * (BN / 2) + (el & 31), cur.z1, cur.z2);
+        }
+        if (!more) break;
+        cur = nxt;
+        t = tnx;
     }
-    epilogue<NJ, MI>(d, acc, m0 + wm * (32 * MI) + 4 * lh, n0 + wn * (BN / 2) + lr, z1, z2);
+}
+
+// resident workgroups of a kernel on this device (CUs x occupancy), cached per kernel
+template <typename K>
+static int resident_blocks(K kernel, int threads) {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) return 0;
+    return cus * per;
+}
+
+template <int BM, int BN, int PREC, int WM, bool VEC, bool SEG>
+static void launch_bf(const GemmArgs& g, hipStream_t st) {
+    static const int resident = resident_blocks(k_gemm_bf<BM, BN, PREC, WM, VEC, SEG>, WM * 128);
+    const int total = g.tiles_m * g.tiles_n * g.d.batch;
+    const int blocks = resident > 0 ? std::min(total, resident) : total;
+    hipLaunchKernelGGL((k_gemm_bf<BM, BN, PREC, WM, VEC, SEG>), dim3(blocks), dim3(WM * 128), 0, st, g);
 }
 
 template <int BN, int PREC>
@@ -468,7 +696,16 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     const int bn = narrow ? 64 : 128;
     // 256 x 128 tile (8 waves, 2 workgroups per CU) for every large-M product; 128 x 128 (4 waves) was 4-8 % faster on
     // the isolated M = 16000, N <= 2304 shapes but made no difference inside the step (A/B on one device)
-    const bool tall = d.operand_bf16 && !narrow && d.M >= 2048;
+    // vector epilogue: every result / aux / residual row must split into aligned 8-column groups
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec = d.operand_bf16 && !narrow && (d.N & 7) == 0 && (d.ldc & 7) == 0 && (d.c_s1 & 7) == 0 && (d.c_s2 & 7) == 0 &&
+                     al16(d.C) && al16(d.C_pre) && al16(d.Cb) && al16(d.Cb_lo) &&
+                     (!d.aux || (al16(d.aux) && (d.ld_aux & 3) == 0 && (d.aux_s1 & 3) == 0 && (d.aux_s2 & 3) == 0)) &&
+                     (!d.residual || (al16(d.residual) && (d.ld_res & 3) == 0 && (d.res_s1 & 3) == 0 && (d.res_s2 & 3) == 0)) &&
+                     (!d.bias || (al16(d.bias) && (d.bias_s2 & 3) == 0)) &&
+                     !(d.act == PAA_ACT_GELU_GRAD && d.residual) &&              // one extra operand stream, 32-bit offsets
+                     63 * d.lda < (1ll << 30) && 63 * d.ldb < (1ll << 30) && (int64_t)d.M * d.ldc < (1ll << 30) && (int64_t)d.M * std::max(d.ld_aux, d.ld_res) < (1ll << 30);
+    const bool tall = vec && d.a_kseg <= 0 && d.M >= 2048;
     g.tiles_m = cdiv(d.M, tall ? 256 : G_BM);
     g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
@@ -479,9 +716,20 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         g_prof.variant[g_prof.n] = (tall ? 32 : 0) + (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     }
     if (d.operand_bf16) {
-        if (narrow) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 64, 1, 2>), grid, dim3(256), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 64, 0, 2>), grid, dim3(256), 0, st, g); }
-        else if (tall) { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<256, 128, 1, 4>), grid, dim3(512), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<256, 128, 0, 4>), grid, dim3(512), 0, st, g); }
-        else { if (d.precision) hipLaunchKernelGGL((k_gemm_bf<128, 128, 1, 2>), grid, dim3(256), 0, st, g); else hipLaunchKernelGGL((k_gemm_bf<128, 128, 0, 2>), grid, dim3(256), 0, st, g); }
+        const bool seg = d.a_kseg > 0;          // segmented / windowed A: general loader
+        if (narrow) {
+            if (seg) { if (d.precision) launch_bf<128, 64, 1, 2, false, true>(g, st); else launch_bf<128, 64, 0, 2, false, true>(g, st); }
+            else { if (d.precision) launch_bf<128, 64, 1, 2, false, false>(g, st); else launch_bf<128, 64, 0, 2, false, false>(g, st); }
+        }
+        else if (seg) { if (d.precision) launch_bf<128, 128, 1, 2, false, true>(g, st); else launch_bf<128, 128, 0, 2, false, true>(g, st); }
+        else if (tall) {
+            static const int variant = getenv("PAA_GEMM_V") ? atoi(getenv("PAA_GEMM_V")) : 0;      // measurement knob
+            if (d.precision) launch_bf<256, 128, 1, 4, true, false>(g, st);
+            else if (variant == 1) launch_bf<256, 128, 0, 4, true, false>(g, st);
+            else launch_bf<256, 128, 0, 2, true, false>(g, st);
+        }
+        else if (vec) { if (d.precision) launch_bf<128, 128, 1, 2, true, false>(g, st); else launch_bf<128, 128, 0, 2, true, false>(g, st); }
+        else { if (d.precision) launch_bf<128, 128, 1, 2, false, false>(g, st); else launch_bf<128, 128, 0, 2, false, false>(g, st); }
     } else if (narrow) { if (d.precision) launch_gemm<64, 1>(g, grid, st); else launch_gemm<64, 0>(g, grid, st); }
     else { if (d.precision) launch_gemm<128, 1>(g, grid, st); else launch_gemm<128, 0>(g, grid, st); }
     if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }

@@ -91,4 +91,22 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Branch-free GELU for the bf16-mode GEMM epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// bf16 rounding of the operands it feeds), one v_exp_f32 + one v_rcp_f32, ~20 instructions instead of libm's erff.
+// e = exp(-x^2 / 2) is shared between erf(x / sqrt 2) and the normal pdf of the derivative.
+__device__ __forceinline__ float gelu_cdf_fast(float x, float& e) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    e = __expf(-ax * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    return 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_fast(float x) { float e; return x * gelu_cdf_fast(x, e); }
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float e;
+    const float cdf = gelu_cdf_fast(x, e);
+    return cdf + x * 0.39894228040143268f * e;
+}
+
 }  // namespace paa

@@ -62,6 +62,16 @@ def run(name, M, N, K, lda=None, act=0, pre=False, outf=True, outb=False, prec=0
 if __name__ == "__main__":
     import sys
     modes = [int(a) for a in sys.argv[1:]] or [1]
+    if modes == [2]:      # epilogue share: same product, different outputs
+        for (nm, M, N, K, lda, it) in (("ffn1", 16000, 3072, 768, None, 20), ("qkv", 16000, 2304, 768, None, 20),
+                                       ("outproj", 16000, 768, 768, None, 20), ("ffn2", 16000, 768, 3072, None, 20),
+                                       ("conv1", 512000, 512, 1536, 1024, 5)):
+            run(nm + " bf16 out only", M, N, K, lda=lda, outf=False, outb=True, iters=it)
+            run(nm + " f32 out only", M, N, K, lda=lda, iters=it)
+            run(nm + " f32 + resid", M, N, K, lda=lda, resid=True, iters=it)
+            run(nm + " gelu pre+bf16", M, N, K, lda=lda, act=1, pre=True, outf=False, outb=True, iters=it)
+            run(nm + " gelugrad f32", M, N, K, lda=lda, act=2, iters=it)
+        sys.exit(0)
     for mode in modes:
       for prec in (0, 1):
         run("w1_t (N=768,K=3072) resid", 16000, 768, 3072, resid=True, prec=prec)
