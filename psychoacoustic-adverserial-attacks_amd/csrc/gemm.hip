@@ -472,7 +472,8 @@ __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned s
 
 // Plain K-contiguous rows through a buffer resource that starts at the tile's first row and ends with the operand:
 // one 32-bit per-lane byte offset for the whole product, everything else scalar; rows past the operand's end
-// (last M / N tile) read zeros from the hardware bounds check instead of branching.
+// (last M / N tile) read zeros from the hardware bounds check instead of branching (the check covers the SGPR
+// offset too: probed with tools/scratch/buf_test.hip).  K must be a multiple of the 64-wide K tile.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const unsigned short* base, int64_t elems) {
     const int64_t bytes = elems > 0 ? 2 * elems : 0;
@@ -481,11 +482,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const unsigned short
 }
 template <int ROWS, int NT>
 __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned k0_bytes, unsigned step_bytes,
-                                         bool kok, uint4 (&v)[ROWS * 8 / NT]) {
+                                         uint4 (&v)[ROWS * 8 / NT]) {
 #pragma unroll
     for (int i = 0; i < ROWS * 8 / NT; ++i) {
         const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, k0_bytes + i * step_bytes, 0);
-        v[i] = kok ? make_uint4(x.x, x.y, x.z, x.w) : make_uint4(0u, 0u, 0u, 0u);
+        v[i] = make_uint4(x.x, x.y, x.z, x.w);
     }
 }
 
@@ -550,12 +551,11 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
             const unsigned kc = (unsigned)((tid & 7) << 3);
             const unsigned va = 2u * ((unsigned)(tid >> 3) * (unsigned)d.lda + kc), vb = 2u * ((unsigned)(tid >> 3) * (unsigned)d.ldb + kc);
             const unsigned sa = 2u * (NT / 8) * (unsigned)d.lda, sb = 2u * (NT / 8) * (unsigned)d.ldb;
-            const bool kok = k0 + (int)kc < d.K;
-            load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A) + a0, ae), va, 2u * k0, sa, kok, rah);
-            load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * k0, sb, kok, rbh);
+            load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A) + a0, ae), va, 2u * k0, sa, rah);
+            load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * k0, sb, rbh);
             if constexpr (PREC) {
-                load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A_lo) + a0, ae), va, 2u * k0, sa, kok, ral);
-                load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B_lo) + b0, be), vb, 2u * k0, sb, kok, rbl);
+                load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A_lo) + a0, ae), va, 2u * k0, sa, ral);
+                load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B_lo) + b0, be), vb, 2u * k0, sb, rbl);
             }
         }
     };
@@ -594,30 +594,60 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
             const bool last = kt + 1 == nk;
             if (!last) load_tile(cur, (kt + 1) * H_BK, tid);
             else if (more) load_tile(nxt, 0, tid);
-#pragma unroll
-            for (int ks = 0; ks < H_BK / 16; ++ks) {
-                bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int off = (wm * (32 * MI) + i * 32 + lr) * H_LD + ks * 16 + lh * 8;
-                    ah[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
-                    if (PREC) al[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
-                }
+            // Fragment reads run one MFMA group ahead of their use: while the MFMAs of (ks, i) issue, the A fragment
+            // of the next (ks, i) — and at the end of a ks step the B fragments of the next one — are already on their
+            // way from LDS.  The sched_group_barrier chain pins that interleaving (1 read group : 1 MFMA group).
+            {
+                constexpr int KS = H_BK / 16;
+                constexpr int NM = NJ * (PREC ? 3 : 1);                  // MFMAs per (ks, i)
+                const unsigned short* pa = sAh + (wm * (32 * MI) + lr) * H_LD + lh * 8;
+                const unsigned short* pb = sBh + (wn * (BN / 2) + lr) * H_LD + lh * 8;
+                constexpr int LO_A = BM * H_LD, LO_B = BN * H_LD;        // hi -> lo plane distance (PREC only)
+                bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int off = (wn * (BN / 2) + j * 32 + lr) * H_LD + ks * 16 + lh * 8;
-                    bh[j] = *reinterpret_cast<const bf16x8*>(sBh + off);
-                    if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sBl + off);
+                    bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD);
+                    if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(pb + LO_B + j * 32 * H_LD);
+                    bhn[j] = bh[j]; bln[j] = bl[j];
                 }
+                ah = *reinterpret_cast<const bf16x8*>(pa);
+                if (PREC) al = *reinterpret_cast<const bf16x8*>(pa + LO_A);
+                ahn = ah; aln = al;
+                __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        if (PREC) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MI; ++i) {
+                        const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
+                        if (nks < KS) {
+                            ahn = *reinterpret_cast<const bf16x8*>(pa + ni * 32 * H_LD + nks * 16);
+                            if (PREC) aln = *reinterpret_cast<const bf16x8*>(pa + LO_A + ni * 32 * H_LD + nks * 16);
+                            if (ni == 0) {
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j) {
+                                    bhn[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD + nks * 16);
+                                    if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(pb + LO_B + j * 32 * H_LD + nks * 16);
+                                }
+                            }
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if (PREC) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                        }
+                        if (nks < KS) {
+                            if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
+                            else __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+                        ah = ahn; al = aln;
+                        if (ni == 0) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) { bh[j] = bhn[j]; bl[j] = bln[j]; }
+                        }
                     }
             }
             __syncthreads();                                   // every wave is done with K tile kt
@@ -634,6 +664,278 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
         cur = nxt;
         t = tnx;
     }
+}
+
+// ---- 256 x 256 x 64 tile, LDS-DMA operand ring (bf16 mode, regular shapes) -------------------------------------------
+// ONE workgroup per CU: 8 waves as 2 (M) x 4 (N), 128 x 64 per wave (8 accumulators = 128 registers, 0.75 fragment
+// reads per MFMA).  Operand K tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write)
+// into a 2-stage ring of 64 KB; the DMA of K tile k+1 (or of the next output tile's first K tile) is issued right after
+// the barrier that opens iteration k, so it has the whole iteration to land, and one barrier per K tile suffices.
+// LDS rows are unpadded 128-byte K slices; bank conflicts are removed by an XOR swizzle applied to the SOURCE chunk
+// (position p = lane&7 of LDS row r receives global chunk p ^ ((r>>1)&7)) and undone in the fragment reads.  The B rows
+// are also permuted inside each 64-row group exactly as store_bf<PERM> does, for the vector epilogue.
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void hard_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512, 2) void k_gemm_dma(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, NW = 8, MI = 4, NJ = 2, NS = 2;
+    constexpr int ROWS = BM + BN;                         // A rows then B rows
+    constexpr int GPW = ROWS / 8 / NW;                    // DMA wave-instructions (8 rows each) per wave per K tile = 8
+    constexpr int STAGE = ROWS * 128;                     // bytes
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+
+    const paa_gemm_desc& d = g.d;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int total = nwg * d.batch;
+    const int nk = d.K / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    struct Tile { int m0, n0, z1, z2; };
+    auto decode = [&](int t) {
+        Tile c;
+        const int z = t / nwg, orig = t - z * nwg;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+        c.m0 = tm * BM; c.n0 = tn * BN;
+        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
+        return c;
+    };
+
+    // ---- load cursor: (tile lt, K tile lk) is the next piece to fetch ---------------------------------------------
+    int lt = blockIdx.x, lk = 0;
+    if (lt >= total) return;
+    const unsigned short* src[GPW];
+    auto set_src = [&](int t) {
+        const Tile c = decode(t);
+        const unsigned short* A = reinterpret_cast<const unsigned short*>(d.A) + c.z1 * d.a_s1 + c.z2 * d.a_s2;
+        const unsigned short* B = reinterpret_cast<const unsigned short*>(d.B) + c.z1 * d.b_s1 + c.z2 * d.b_s2;
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const int r = (i * NW + wave) * 8 + (lane >> 3);          // ring row: [0, BM) A, [BM, BM + BN) B
+            const int ch = (lane & 7) ^ ((r >> 1) & 7);               // global chunk that lands at position lane & 7
+            if (i * NW * 8 < BM) {                                    // (i * NW + wave) * 8 < BM for every wave: A
+                src[i] = A + (int64_t)min(c.m0 + r, d.M - 1) * d.lda + ch * 8;
+            } else {
+                const int p = r - BM;
+                const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);
+                src[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
+            }
+        }
+    };
+    auto issue = [&](int stage) {
+        unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < GPW; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lk * 64), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
+        if (++lk == nk) {
+            lk = 0;
+            lt += gridDim.x;
+            if (lt < total) set_src(lt);
+        }
+    };
+    set_src(lt);
+    issue(0);
+
+    // fragment addressing: row base + swizzled 16-byte chunk of the K step
+    const int sw = (lr >> 1) & 7;
+    int offk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
+    const int arow = (wm * 128 + lr) * 128, brow = BM * 128 + (wn * 64 + lr) * 128;
+
+    int it = 0;                                            // K tiles consumed so far: ring stage = it & 1
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const Tile cur = decode(t);
+        f32x16 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            wait_vmcnt<0>();                               // my pieces of this K tile have landed
+            hard_barrier();                                // everyone's have; everyone is done with the other stage
+            if (lt < total) issue((it + 1) & 1);
+            const unsigned char* sa = smem + (it & 1) * STAGE + arow;
+            const unsigned char* sb = smem + (it & 1) * STAGE + brow;
+            bf16x8 bh[NJ], bhn[NJ], ah, ahn;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { bh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[0]); bhn[j] = bh[j]; }
+            ah = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
+            ahn = ah;
+            __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
+                    if (nks < 4) {
+                        ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 4096 + offk[nks]);
+                        if (ni == 0) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[nks]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    if (nks < 4) {
+                        if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+                    ah = ahn;
+                    if (ni == 0) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) bh[j] = bhn[j];
+                    }
+                }
+        }
+        epilogue_vec<MI, true>(d, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, cur.z1, cur.z2, lane);
+    }
+}
+
+// ---- 256 x 256 x 64 tile, two-deep register prefetch + double-buffered LDS (bf16 mode, regular shapes) ------------------
+// ONE workgroup per CU: 8 waves as 2 (M) x 4 (N), 128 x 64 per wave.  The operand stream is a flat sequence of
+// (output tile, K tile) pieces walked by a load cursor that runs TWO pieces ahead of the MFMAs: piece n+2 is requested
+// (buffer loads into one of two register sets) when iteration n opens, and written to the idle LDS buffer at the end of
+// iteration n+1, so a load has almost two iterations (~2 us) to arrive; one barrier per K tile.  Output-tile boundaries
+// do not drain the pipeline: the next tile's first two K tiles are already in LDS / in flight during the epilogue.
+__global__ __launch_bounds__(512, 2) void k_gemm_big(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, NT = 512, MI = 4, NJ = 2;
+    constexpr int BUF = (BM + BN) * H_LD;                  // bf16 elements per LDS buffer (73,728 B)
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+
+    const paa_gemm_desc& d = g.d;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int total = nwg * d.batch;
+    const int nk = d.K / H_BK;
+    struct Tile { int m0, n0, z1, z2; };
+    auto decode = [&](int t) {
+        Tile c;
+        const int z = t / nwg, orig = t - z * nwg;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+        c.m0 = tm * BM; c.n0 = tn * BN;
+        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
+        return c;
+    };
+    int t = blockIdx.x;
+    if (t >= total) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // ---- load cursor ------------------------------------------------------------------------------------------------
+    int lt = t, lk = 0;
+    Tile lc = decode(lt);
+    const unsigned kc = (unsigned)((tid & 7) << 3);
+    const unsigned va = 2u * ((unsigned)(tid >> 3) * (unsigned)d.lda + kc), vb = 2u * ((unsigned)(tid >> 3) * (unsigned)d.ldb + kc);
+    const unsigned sa = 2u * (NT / 8) * (unsigned)d.lda, sb = 2u * (NT / 8) * (unsigned)d.ldb;
+    auto gload = [&](uint4 (&ra)[4], uint4 (&rb)[4]) {
+        if (lt >= total) return;
+        const int64_t a0 = lc.z1 * d.a_s1 + lc.z2 * d.a_s2 + (int64_t)lc.m0 * d.lda, b0 = lc.z1 * d.b_s1 + lc.z2 * d.b_s2 + (int64_t)lc.n0 * d.ldb;
+        const int64_t ae = (int64_t)(d.M - 1 - lc.m0) * d.lda + d.K, be = (int64_t)(d.N - 1 - lc.n0) * d.ldb + d.K;
+        load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A) + a0, ae), va, 2u * H_BK * lk, sa, ra);
+        load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * H_BK * lk, sb, rb);
+        if (++lk == nk) {
+            lk = 0;
+            lt += gridDim.x;
+            if (lt < total) lc = decode(lt);
+        }
+    };
+    auto lstore = [&](unsigned short* buf, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
+        store_bf<BM, NT, false>(buf, ra, tid);
+        store_bf<BN, NT, true>(buf + BM * H_LD, rb, tid);
+    };
+
+    f32x16 acc[MI][NJ];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    auto compute = [&](const unsigned short* buf) {
+        const unsigned short* pa = buf + (wm * 128 + lr) * H_LD + lh * 8;
+        const unsigned short* pb = buf + BM * H_LD + (wn * 64 + lr) * H_LD + lh * 8;
+        bf16x8 bh[NJ], bhn[NJ], ah, ahn;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD); bhn[j] = bh[j]; }
+        ah = *reinterpret_cast<const bf16x8*>(pa);
+        ahn = ah;
+        __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
+                if (nks < 4) {
+                    ahn = *reinterpret_cast<const bf16x8*>(pa + ni * 32 * H_LD + nks * 16);
+                    if (ni == 0) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) bhn[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD + nks * 16);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                if (nks < 4) {
+                    if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+                ah = ahn;
+                if (ni == 0) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bh[j] = bhn[j];
+                }
+            }
+    };
+
+    const int my_tiles = (total - t + (int)gridDim.x - 1) / (int)gridDim.x;
+    int rem = my_tiles * nk;                               // iterations left, including the current one
+    uint4 r0a[4], r0b[4], r1a[4], r1b[4];
+    gload(r0a, r0b);
+    gload(r1a, r1b);
+    lstore(smem, r0a, r0b);
+    Tile cur = decode(t);
+    int k = 0;
+    zero_acc();
+
+#define PAA_PHASE(BUFC, BUFN, RFA, RFB, RNA, RNB)                                                              \
+    {                                                                                                          \
+        __syncthreads();               /* BUFC complete; everyone has left BUFN */                            \
+        gload(RFA, RFB);               /* piece n+2 into the set that was written to LDS last iteration */    \
+        compute(BUFC);                                                                                         \
+        if (rem > 1) lstore(BUFN, RNA, RNB);   /* piece n+1: requested one iteration ago */                   \
+        --rem;                                                                                                 \
+        if (++k == nk) {                                                                                       \
+            epilogue_vec<MI, true>(d, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, cur.z1, cur.z2, lane);         \
+            if (rem == 0) break;                                                                               \
+            k = 0; t += gridDim.x; cur = decode(t);                                                            \
+            zero_acc();                                                                                        \
+        }                                                                                                      \
+    }
+    for (;;) {
+        PAA_PHASE(smem, smem + BUF, r0a, r0b, r1a, r1b)
+        PAA_PHASE(smem + BUF, smem, r1a, r1b, r0a, r0b)
+    }
+#undef PAA_PHASE
 }
 
 // resident workgroups of a kernel on this device (CUs x occupancy), cached per kernel
@@ -705,7 +1007,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
                      (!d.bias || (al16(d.bias) && (d.bias_s2 & 3) == 0)) &&
                      !(d.act == PAA_ACT_GELU_GRAD && d.residual) &&              // one extra operand stream, 32-bit offsets
                      63 * d.lda < (1ll << 30) && 63 * d.ldb < (1ll << 30) && (int64_t)d.M * d.ldc < (1ll << 30) && (int64_t)d.M * std::max(d.ld_aux, d.ld_res) < (1ll << 30);
-    const bool tall = vec && d.a_kseg <= 0 && d.M >= 2048;
+    const bool tall = vec && d.a_kseg <= 0 && (d.K & 63) == 0 && d.M >= 2048;
     g.tiles_m = cdiv(d.M, tall ? 256 : G_BM);
     g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
@@ -716,7 +1018,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         g_prof.variant[g_prof.n] = (tall ? 32 : 0) + (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     }
     if (d.operand_bf16) {
-        const bool seg = d.a_kseg > 0;          // segmented / windowed A: general loader
+        const bool seg = d.a_kseg > 0 || (d.K & 63);          // segmented / windowed A or a K tail: general loader
         if (narrow) {
             if (seg) { if (d.precision) launch_bf<128, 64, 1, 2, false, true>(g, st); else launch_bf<128, 64, 0, 2, false, true>(g, st); }
             else { if (d.precision) launch_bf<128, 64, 1, 2, false, false>(g, st); else launch_bf<128, 64, 0, 2, false, false>(g, st); }
@@ -726,6 +1028,18 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             static const int variant = getenv("PAA_GEMM_V") ? atoi(getenv("PAA_GEMM_V")) : 0;      // measurement knob
             if (d.precision) launch_bf<256, 128, 1, 4, true, false>(g, st);
             else if (variant == 1) launch_bf<256, 128, 0, 4, true, false>(g, st);
+            else if (variant == 2 && d.N >= 256) {
+                static const int resident = resident_blocks(k_gemm_dma, 512);
+                g.tiles_m = cdiv(d.M, 256); g.tiles_n = cdiv(d.N, 256);
+                const int total = g.tiles_m * g.tiles_n * d.batch;
+                hipLaunchKernelGGL(k_gemm_dma, dim3(resident > 0 ? std::min(total, resident) : total), dim3(512), 0, st, g);
+            }
+            else if (variant == 3 && d.N >= 256) {
+                static const int resident = resident_blocks(k_gemm_big, 512);
+                g.tiles_m = cdiv(d.M, 256); g.tiles_n = cdiv(d.N, 256);
+                const int total = g.tiles_m * g.tiles_n * d.batch;
+                hipLaunchKernelGGL(k_gemm_big, dim3(resident > 0 ? std::min(total, resident) : total), dim3(512), 0, st, g);
+            }
             else launch_bf<256, 128, 0, 2, true, false>(g, st);
         }
         else if (vec) { if (d.precision) launch_bf<128, 128, 1, 2, true, false>(g, st); else launch_bf<128, 128, 0, 2, true, false>(g, st); }
