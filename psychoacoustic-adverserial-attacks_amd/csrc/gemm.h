@@ -60,6 +60,9 @@ typedef struct paa_gemm_desc {
     // C itself may be null when only the bf16 result is wanted.
     void* Cb;
     void* Cb_lo;
+    // aux_bf16 != 0: C_pre and aux are bf16 arrays (uint16 bit patterns, same leading dimensions / strides in
+    // elements): the pre-activation a GELU product keeps for its backward pass is stored at half the bytes (bf16 mode).
+    int32_t aux_bf16;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

@@ -38,10 +38,14 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
     // mw / nw: first row / column this lane owns
     const int64_t coff = z1 * d.c_s1 + z2 * d.c_s2 + (int64_t)mw * d.ldc + nw;
     float* __restrict__ C = d.C ? d.C + coff : nullptr;
-    float* __restrict__ Cp = d.C_pre ? d.C_pre + coff : nullptr;
+    const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored as bf16
+    float* __restrict__ Cp = (d.C_pre && !x16) ? d.C_pre + coff : nullptr;
+    unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + coff : nullptr;
     unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + coff : nullptr;
     unsigned short* __restrict__ Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + coff : nullptr;
-    const float* __restrict__ aux = d.aux ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2 + (int64_t)mw * d.ld_aux + nw : nullptr;
+    const int64_t xoff = z1 * d.aux_s1 + z2 * d.aux_s2 + (int64_t)mw * d.ld_aux + nw;
+    const float* __restrict__ aux = (d.aux && !x16) ? d.aux + xoff : nullptr;
+    const unsigned short* __restrict__ aux16 = (d.aux && x16) ? reinterpret_cast<const unsigned short*>(d.aux) + xoff : nullptr;
     const float* __restrict__ res = d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 + (int64_t)mw * d.ld_res + nw : nullptr;
     const float* __restrict__ bias = d.bias ? d.bias + z2 * d.bias_s2 + nw : nullptr;
     const int ldc = (int)d.ldc, ld_aux = (int)d.ld_aux, ld_res = (int)d.ld_res;
@@ -55,6 +59,8 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
         const int64_t ro = (int64_t)(i * 32) * ldc;
         float* __restrict__ Ci = C ? C + ro : nullptr;
         float* __restrict__ Cpi = Cp ? Cp + ro : nullptr;
+        unsigned short* __restrict__ Cpi16 = Cp16 ? Cp16 + ro : nullptr;
+        const unsigned short* __restrict__ auxi16 = aux16 ? aux16 + (int64_t)(i * 32) * ld_aux : nullptr;
         unsigned short* __restrict__ Cbi = Cb ? Cb + ro : nullptr;
         unsigned short* __restrict__ Cbli = Cbl ? Cbl + ro : nullptr;
         const float* __restrict__ auxi = aux ? aux + (int64_t)(i * 32) * ld_aux : nullptr;
@@ -69,7 +75,7 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int dm = (e & 3) + 8 * (e >> 2);
-                    ax[e] = (mw + i * 32 + dm < d.M) ? auxi[dm * ld_aux + dn] : 0.f;
+                    ax[e] = (mw + i * 32 + dm < d.M) ? (auxi16 ? bf16_to_f32(auxi16[dm * ld_aux + dn]) : auxi[dm * ld_aux + dn]) : 0.f;
                 }
             }
 #pragma unroll
@@ -86,6 +92,7 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
                 }
                 if (act == PAA_ACT_GELU) {
                     if (Cpi) Cpi[ci] = dead ? 0.f : v;
+                    if (Cpi16) Cpi16[ci] = dead ? (unsigned short)0 : bf16_bits(v);
                     v = gelu_f(v);
                 } else if (act == PAA_ACT_GELU_GRAD) {
                     v *= gelu_grad_f(ax[e]);
@@ -326,11 +333,15 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
     const bool gg = act == PAA_ACT_GELU_GRAD;
     const int64_t cbase = z1 * d.c_s1 + z2 * d.c_s2;
     float* __restrict__ C = d.C ? d.C + cbase : nullptr;
-    float* __restrict__ Cp = d.C_pre ? d.C_pre + cbase : nullptr;
+    const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored as bf16
+    float* __restrict__ Cp = (d.C_pre && !x16) ? d.C_pre + cbase : nullptr;
+    unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + cbase : nullptr;
     unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + cbase : nullptr;
     unsigned short* __restrict__ Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + cbase : nullptr;
-    const float* __restrict__ ex = gg ? d.aux + z1 * d.aux_s1 + z2 * d.aux_s2
+    const bool ex16 = gg && x16;                        // the extra stream is bf16: 8 columns = one 16-byte vector
+    const float* __restrict__ ex = gg ? (ex16 ? nullptr : d.aux + z1 * d.aux_s1 + z2 * d.aux_s2)
                                       : (d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr);
+    const unsigned short* __restrict__ exh = ex16 ? reinterpret_cast<const unsigned short*>(d.aux) + z1 * d.aux_s1 + z2 * d.aux_s2 : nullptr;
     const unsigned ldc = (unsigned)d.ldc, ldx = (unsigned)(gg ? d.ld_aux : d.ld_res);
     const unsigned co = (unsigned)row0 * ldc + (unsigned)col;
     const unsigned xo = (unsigned)row0 * ldx + (unsigned)col;
@@ -348,15 +359,19 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
     const float alpha = d.alpha;
     const bool accum = d.accumulate != 0;
     constexpr int NG = 4 * MI;                           // row groups of 8 rows: (i, g)
-    float4 xv[2][2];
+    uint4 xv[2][2];                                       // raw bits: 2 x float4, or one uint4 of 8 bf16 in [0]
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { xv[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); xv[u][1] = xv[u][0]; }
-    auto fetch = [&](int grp, float4 (&v2)[2]) {
+    for (int u = 0; u < 2; ++u) { xv[u][0] = make_uint4(0u, 0u, 0u, 0u); xv[u][1] = xv[u][0]; }
+    auto fetch = [&](int grp, uint4 (&v2)[2]) {
         const int dm = (grp >> 2) * 32 + (grp & 3) * 8;
-        if (ex && col_ok && row0 + dm < d.M) {
+        if (col_ok && row0 + dm < d.M) {
             const unsigned o = xo + (unsigned)dm * ldx;
-            v2[0] = *reinterpret_cast<const float4*>(ex + o);
-            v2[1] = *reinterpret_cast<const float4*>(ex + o + 4u);
+            if (ex) {
+                v2[0] = *reinterpret_cast<const uint4*>(ex + o);
+                v2[1] = *reinterpret_cast<const uint4*>(ex + o + 4u);
+            } else if (exh) {
+                v2[0] = *reinterpret_cast<const uint4*>(exh + o);
+            }
         }
     };
     fetch(0, xv[0]);
@@ -373,18 +388,30 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
             dead = rem >= d.row_valid;
         }
         const unsigned ci = co + (unsigned)dm * ldc;
-        unsigned hp[4], lp[4];                               // packed bf16 pairs of the 8 columns
+        unsigned hp[4], lp[4], pp[4];                        // packed bf16 pairs of the 8 columns (result hi / lo, C_pre)
         // the two 4-column halves go through the math one after the other: with the tile's 64 accumulator registers
         // still live there is no room for eight interleaved GELU chains
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float x[4] = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
             quad_transpose(x[0], x[1], x[2], x[3], o1, o2);   // every lane takes part, whatever its bounds
-            const float e4[4] = {xv[u][j].x, xv[u][j].y, xv[u][j].z, xv[u][j].w};
+            float e4[4];
+            if (ex16) {
+                const unsigned w0 = j ? xv[u][0].z : xv[u][0].x, w1 = j ? xv[u][0].w : xv[u][0].y;
+                e4[0] = __uint_as_float(w0 << 16); e4[1] = __uint_as_float(w0 & 0xFFFF0000u);
+                e4[2] = __uint_as_float(w1 << 16); e4[3] = __uint_as_float(w1 & 0xFFFF0000u);
+            } else {
+                e4[0] = __uint_as_float(xv[u][j].x); e4[1] = __uint_as_float(xv[u][j].y);
+                e4[2] = __uint_as_float(xv[u][j].z); e4[3] = __uint_as_float(xv[u][j].w);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = x[k] * alpha + bv[4 * j + k];
             if (act == PAA_ACT_GELU) {
                 if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(x[0], x[1], x[2], x[3]);
+                if (Cp16) {
+                    pp[2 * j] = dead ? 0u : (bf16_bits(x[0]) | ((unsigned)bf16_bits(x[1]) << 16));
+                    pp[2 * j + 1] = dead ? 0u : (bf16_bits(x[2]) | ((unsigned)bf16_bits(x[3]) << 16));
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) x[k] = FAST ? gelu_fast(x[k]) : gelu_f(x[k]);
                 if (ex) {
@@ -423,6 +450,7 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (Cp16 && live && act == PAA_ACT_GELU) *reinterpret_cast<uint4*>(Cp16 + ci) = make_uint4(pp[0], pp[1], pp[2], pp[3]);
         if (Cb && live) {
             *reinterpret_cast<uint4*>(Cb + ci) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
             if (Cbl) *reinterpret_cast<uint4*>(Cbl + ci) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
@@ -666,278 +694,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     }
 }
 
-// ---- 256 x 256 x 64 tile, LDS-DMA operand ring (bf16 mode, regular shapes) -------------------------------------------
-// ONE workgroup per CU: 8 waves as 2 (M) x 4 (N), 128 x 64 per wave (8 accumulators = 128 registers, 0.75 fragment
-// reads per MFMA).  Operand K tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write)
-// into a 2-stage ring of 64 KB; the DMA of K tile k+1 (or of the next output tile's first K tile) is issued right after
-// the barrier that opens iteration k, so it has the whole iteration to land, and one barrier per K tile suffices.
-// LDS rows are unpadded 128-byte K slices; bank conflicts are removed by an XOR swizzle applied to the SOURCE chunk
-// (position p = lane&7 of LDS row r receives global chunk p ^ ((r>>1)&7)) and undone in the fragment reads.  The B rows
-// are also permuted inside each 64-row group exactly as store_bf<PERM> does, for the vector epilogue.
-typedef __attribute__((address_space(1))) const void* gas_ptr;
-typedef __attribute__((address_space(3))) void* las_ptr;
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void hard_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__global__ __launch_bounds__(512, 2) void k_gemm_dma(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NW = 8, MI = 4, NJ = 2, NS = 2;
-    constexpr int ROWS = BM + BN;                         // A rows then B rows
-    constexpr int GPW = ROWS / 8 / NW;                    // DMA wave-instructions (8 rows each) per wave per K tile = 8
-    constexpr int STAGE = ROWS * 128;                     // bytes
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int total = nwg * d.batch;
-    const int nk = d.K / 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    struct Tile { int m0, n0, z1, z2; };
-    auto decode = [&](int t) {
-        Tile c;
-        const int z = t / nwg, orig = t - z * nwg;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-        c.m0 = tm * BM; c.n0 = tn * BN;
-        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
-        return c;
-    };
-
-    // ---- load cursor: (tile lt, K tile lk) is the next piece to fetch ---------------------------------------------
-    int lt = blockIdx.x, lk = 0;
-    if (lt >= total) return;
-    const unsigned short* src[GPW];
-    auto set_src = [&](int t) {
-        const Tile c = decode(t);
-        const unsigned short* A = reinterpret_cast<const unsigned short*>(d.A) + c.z1 * d.a_s1 + c.z2 * d.a_s2;
-        const unsigned short* B = reinterpret_cast<const unsigned short*>(d.B) + c.z1 * d.b_s1 + c.z2 * d.b_s2;
-#pragma unroll
-        for (int i = 0; i < GPW; ++i) {
-            const int r = (i * NW + wave) * 8 + (lane >> 3);          // ring row: [0, BM) A, [BM, BM + BN) B
-            const int ch = (lane & 7) ^ ((r >> 1) & 7);               // global chunk that lands at position lane & 7
-            if (i * NW * 8 < BM) {                                    // (i * NW + wave) * 8 < BM for every wave: A
-                src[i] = A + (int64_t)min(c.m0 + r, d.M - 1) * d.lda + ch * 8;
-            } else {
-                const int p = r - BM;
-                const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);
-                src[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
-            }
-        }
-    };
-    auto issue = [&](int stage) {
-        unsigned char* st = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < GPW; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lk * 64), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
-        if (++lk == nk) {
-            lk = 0;
-            lt += gridDim.x;
-            if (lt < total) set_src(lt);
-        }
-    };
-    set_src(lt);
-    issue(0);
-
-    // fragment addressing: row base + swizzled 16-byte chunk of the K step
-    const int sw = (lr >> 1) & 7;
-    int offk[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
-    const int arow = (wm * 128 + lr) * 128, brow = BM * 128 + (wn * 64 + lr) * 128;
-
-    int it = 0;                                            // K tiles consumed so far: ring stage = it & 1
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const Tile cur = decode(t);
-        f32x16 acc[MI][NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        for (int kt = 0; kt < nk; ++kt, ++it) {
-            wait_vmcnt<0>();                               // my pieces of this K tile have landed
-            hard_barrier();                                // everyone's have; everyone is done with the other stage
-            if (lt < total) issue((it + 1) & 1);
-            const unsigned char* sa = smem + (it & 1) * STAGE + arow;
-            const unsigned char* sb = smem + (it & 1) * STAGE + brow;
-            bf16x8 bh[NJ], bhn[NJ], ah, ahn;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { bh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[0]); bhn[j] = bh[j]; }
-            ah = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
-            ahn = ah;
-            __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
-                    if (nks < 4) {
-                        ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 4096 + offk[nks]);
-                        if (ni == 0) {
-#pragma unroll
-                            for (int j = 0; j < NJ; ++j) bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[nks]);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                    if (nks < 4) {
-                        if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
-                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
-                    ah = ahn;
-                    if (ni == 0) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) bh[j] = bhn[j];
-                    }
-                }
-        }
-        epilogue_vec<MI, true>(d, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, cur.z1, cur.z2, lane);
-    }
-}
-
-// ---- 256 x 256 x 64 tile, two-deep register prefetch + double-buffered LDS (bf16 mode, regular shapes) ------------------
-// ONE workgroup per CU: 8 waves as 2 (M) x 4 (N), 128 x 64 per wave.  The operand stream is a flat sequence of
-// (output tile, K tile) pieces walked by a load cursor that runs TWO pieces ahead of the MFMAs: piece n+2 is requested
-// (buffer loads into one of two register sets) when iteration n opens, and written to the idle LDS buffer at the end of
-// iteration n+1, so a load has almost two iterations (~2 us) to arrive; one barrier per K tile.  Output-tile boundaries
-// do not drain the pipeline: the next tile's first two K tiles are already in LDS / in flight during the epilogue.
-__global__ __launch_bounds__(512, 2) void k_gemm_big(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NT = 512, MI = 4, NJ = 2;
-    constexpr int BUF = (BM + BN) * H_LD;                  // bf16 elements per LDS buffer (73,728 B)
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int total = nwg * d.batch;
-    const int nk = d.K / H_BK;
-    struct Tile { int m0, n0, z1, z2; };
-    auto decode = [&](int t) {
-        Tile c;
-        const int z = t / nwg, orig = t - z * nwg;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-        c.m0 = tm * BM; c.n0 = tn * BN;
-        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
-        return c;
-    };
-    int t = blockIdx.x;
-    if (t >= total) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    // ---- load cursor ------------------------------------------------------------------------------------------------
-    int lt = t, lk = 0;
-    Tile lc = decode(lt);
-    const unsigned kc = (unsigned)((tid & 7) << 3);
-    const unsigned va = 2u * ((unsigned)(tid >> 3) * (unsigned)d.lda + kc), vb = 2u * ((unsigned)(tid >> 3) * (unsigned)d.ldb + kc);
-    const unsigned sa = 2u * (NT / 8) * (unsigned)d.lda, sb = 2u * (NT / 8) * (unsigned)d.ldb;
-    auto gload = [&](uint4 (&ra)[4], uint4 (&rb)[4]) {
-        if (lt >= total) return;
-        const int64_t a0 = lc.z1 * d.a_s1 + lc.z2 * d.a_s2 + (int64_t)lc.m0 * d.lda, b0 = lc.z1 * d.b_s1 + lc.z2 * d.b_s2 + (int64_t)lc.n0 * d.ldb;
-        const int64_t ae = (int64_t)(d.M - 1 - lc.m0) * d.lda + d.K, be = (int64_t)(d.N - 1 - lc.n0) * d.ldb + d.K;
-        load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A) + a0, ae), va, 2u * H_BK * lk, sa, ra);
-        load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * H_BK * lk, sb, rb);
-        if (++lk == nk) {
-            lk = 0;
-            lt += gridDim.x;
-            if (lt < total) lc = decode(lt);
-        }
-    };
-    auto lstore = [&](unsigned short* buf, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
-        store_bf<BM, NT, false>(buf, ra, tid);
-        store_bf<BN, NT, true>(buf + BM * H_LD, rb, tid);
-    };
-
-    f32x16 acc[MI][NJ];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    };
-    auto compute = [&](const unsigned short* buf) {
-        const unsigned short* pa = buf + (wm * 128 + lr) * H_LD + lh * 8;
-        const unsigned short* pb = buf + BM * H_LD + (wn * 64 + lr) * H_LD + lh * 8;
-        bf16x8 bh[NJ], bhn[NJ], ah, ahn;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) { bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD); bhn[j] = bh[j]; }
-        ah = *reinterpret_cast<const bf16x8*>(pa);
-        ahn = ah;
-        __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
-                if (nks < 4) {
-                    ahn = *reinterpret_cast<const bf16x8*>(pa + ni * 32 * H_LD + nks * 16);
-                    if (ni == 0) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) bhn[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD + nks * 16);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                if (nks < 4) {
-                    if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
-                ah = ahn;
-                if (ni == 0) {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) bh[j] = bhn[j];
-                }
-            }
-    };
-
-    const int my_tiles = (total - t + (int)gridDim.x - 1) / (int)gridDim.x;
-    int rem = my_tiles * nk;                               // iterations left, including the current one
-    uint4 r0a[4], r0b[4], r1a[4], r1b[4];
-    gload(r0a, r0b);
-    gload(r1a, r1b);
-    lstore(smem, r0a, r0b);
-    Tile cur = decode(t);
-    int k = 0;
-    zero_acc();
-
-#define PAA_PHASE(BUFC, BUFN, RFA, RFB, RNA, RNB)                                                              \
-    {                                                                                                          \
-        __syncthreads();               /* BUFC complete; everyone has left BUFN */                            \
-        gload(RFA, RFB);               /* piece n+2 into the set that was written to LDS last iteration */    \
-        compute(BUFC);                                                                                         \
-        if (rem > 1) lstore(BUFN, RNA, RNB);   /* piece n+1: requested one iteration ago */                   \
-        --rem;                                                                                                 \
-        if (++k == nk) {                                                                                       \
-            epilogue_vec<MI, true>(d, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, cur.z1, cur.z2, lane);         \
-            if (rem == 0) break;                                                                               \
-            k = 0; t += gridDim.x; cur = decode(t);                                                            \
-            zero_acc();                                                                                        \
-        }                                                                                                      \
-    }
-    for (;;) {
-        PAA_PHASE(smem, smem + BUF, r0a, r0b, r1a, r1b)
-        PAA_PHASE(smem + BUF, smem, r1a, r1b, r0a, r0b)
-    }
-#undef PAA_PHASE
-}
-
 // resident workgroups of a kernel on this device (CUs x occupancy), cached per kernel
 template <typename K>
 static int resident_blocks(K kernel, int threads) {
@@ -1002,13 +758,23 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool vec = d.operand_bf16 && !narrow && (d.N & 7) == 0 && (d.ldc & 7) == 0 && (d.c_s1 & 7) == 0 && (d.c_s2 & 7) == 0 &&
                      al16(d.C) && al16(d.C_pre) && al16(d.Cb) && al16(d.Cb_lo) &&
-                     (!d.aux || (al16(d.aux) && (d.ld_aux & 3) == 0 && (d.aux_s1 & 3) == 0 && (d.aux_s2 & 3) == 0)) &&
+                     (!d.aux || (al16(d.aux) && (d.ld_aux & (d.aux_bf16 ? 7 : 3)) == 0 && (d.aux_s1 & 7) == 0 && (d.aux_s2 & 7) == 0)) &&
                      (!d.residual || (al16(d.residual) && (d.ld_res & 3) == 0 && (d.res_s1 & 3) == 0 && (d.res_s2 & 3) == 0)) &&
                      (!d.bias || (al16(d.bias) && (d.bias_s2 & 3) == 0)) &&
                      !(d.act == PAA_ACT_GELU_GRAD && d.residual) &&              // one extra operand stream, 32-bit offsets
                      63 * d.lda < (1ll << 30) && 63 * d.ldb < (1ll << 30) && (int64_t)d.M * d.ldc < (1ll << 30) && (int64_t)d.M * std::max(d.ld_aux, d.ld_res) < (1ll << 30);
     const bool tall = vec && d.a_kseg <= 0 && (d.K & 63) == 0 && d.M >= 2048;
-    g.tiles_m = cdiv(d.M, tall ? 256 : G_BM);
+    // bf16 mode, large M: 256- or 192-row tiles, whichever wastes fewer workgroup slots in the last round of the
+    // persistent grid (M = 16000, N = 768: 378 tiles of 256 rows leave a quarter of the 512 slots idle, 504 of 192 fill them)
+    bool bm192 = false;
+    if (tall && !d.precision) {
+        static const int slots = std::max(1, resident_blocks(k_gemm_bf<256, 128, 0, 2, true, false>, 256));
+        const int64_t tn = cdiv(d.N, 128);
+        const int64_t t256 = (int64_t)cdiv(d.M, 256) * tn * d.batch, t192 = (int64_t)cdiv(d.M, 192) * tn * d.batch;
+        const double c256 = (double)((t256 + slots - 1) / slots) * 256.0, c192 = (double)((t192 + slots - 1) / slots) * 192.0 * 1.05;
+        bm192 = c192 < c256;
+    }
+    g.tiles_m = cdiv(d.M, tall ? (bm192 ? 192 : 256) : G_BM);
     g.tiles_n = cdiv(d.N, bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
@@ -1025,21 +791,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         }
         else if (seg) { if (d.precision) launch_bf<128, 128, 1, 2, false, true>(g, st); else launch_bf<128, 128, 0, 2, false, true>(g, st); }
         else if (tall) {
-            static const int variant = getenv("PAA_GEMM_V") ? atoi(getenv("PAA_GEMM_V")) : 0;      // measurement knob
             if (d.precision) launch_bf<256, 128, 1, 4, true, false>(g, st);
-            else if (variant == 1) launch_bf<256, 128, 0, 4, true, false>(g, st);
-            else if (variant == 2 && d.N >= 256) {
-                static const int resident = resident_blocks(k_gemm_dma, 512);
-                g.tiles_m = cdiv(d.M, 256); g.tiles_n = cdiv(d.N, 256);
-                const int total = g.tiles_m * g.tiles_n * d.batch;
-                hipLaunchKernelGGL(k_gemm_dma, dim3(resident > 0 ? std::min(total, resident) : total), dim3(512), 0, st, g);
-            }
-            else if (variant == 3 && d.N >= 256) {
-                static const int resident = resident_blocks(k_gemm_big, 512);
-                g.tiles_m = cdiv(d.M, 256); g.tiles_n = cdiv(d.N, 256);
-                const int total = g.tiles_m * g.tiles_n * d.batch;
-                hipLaunchKernelGGL(k_gemm_big, dim3(resident > 0 ? std::min(total, resident) : total), dim3(512), 0, st, g);
-            }
+            else if (bm192) launch_bf<192, 128, 0, 2, true, false>(g, st);
             else launch_bf<256, 128, 0, 2, true, false>(g, st);
         }
         else if (vec) { if (d.precision) launch_bf<128, 128, 1, 2, true, false>(g, st); else launch_bf<128, 128, 0, 2, true, false>(g, st); }

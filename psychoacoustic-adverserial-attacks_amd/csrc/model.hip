@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <map>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,7 @@ struct ConvL {
     std::vector<CBf> wd;               // per residue class of the stride: [cin][(Q+1)*cout]
     std::vector<int> wdQ;
     float *pre = nullptr, *act_f = nullptr, *cv = nullptr, *row_stats = nullptr;
+    bool pre16 = false;                // pre holds bf16 (see paa_model::pre16)
     Bf actb{nullptr, nullptr};
 };
 
@@ -52,6 +54,7 @@ struct EncL {
     CBf wqkv, wqkv_t, wo, wo_t, w1, w1_t, w2, w2_t;
     const float *bqkv, *bo, *ln1_g, *ln1_b, *b1, *b2, *ln2_g, *ln2_b;
     float *qkv = nullptr, *P = nullptr, *ln1_in, *st1, *fpre, *ln2_in, *st2;   // qkv, P: materialised attention only
+                                     // fpre holds bf16 when the model's pre16 flag is set
     Bf qkvH{nullptr, nullptr}, ctxH{nullptr, nullptr};                          // fused attention: bf16 Q|K|V and O
     float* lse = nullptr;
 };
@@ -83,6 +86,8 @@ struct paa_model {
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
     bool fused;                      // flash-style attention kernels (bf16 mode, head_dim 64); else materialised scores
+    bool pre16;                      // bf16 mode: pre-activations kept for GELU backward (L{l}.fpre, and conv{i}.pre, i < last,
+                                     // of the group-norm extractor) are stored as bf16 — they only feed gelu'(.) factors
     std::vector<ConvL> conv;
     std::vector<EncL> enc;
     std::map<std::string, std::pair<const float*, int64_t>> tensors;
@@ -143,6 +148,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     paa_model* m = new paa_model();
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
     m->fused = (m->prec == 0) && (a.hidden / a.heads == 64);
+    m->pre16 = m->prec == 0 && !(getenv("PAA_PRE16") && atoi(getenv("PAA_PRE16")) == 0);      // env: A/B measurement knob
     for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
 
     // ---- shapes: conv output lengths and the padded row counts (P_{i-1} = s_i * P_i) ----
@@ -231,7 +237,8 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         for (int i = 0; i < nc; ++i) {
             ConvL& c = m->conv[i];
             const int64_t n = ((int64_t)B * c.P + GUARD) * c.cout;
-            c.pre = take(n);
+            c.pre16 = m->pre16 && !a.feat_norm_layer && i < nc - 1;
+            c.pre = take(c.pre16 ? (n + 1) / 2 : n);
             if (i < nc - 1) c.actb = take_bf(n); else c.act_f = take(n);
             if (a.feat_norm_layer) { if (i) c.cv = take(n); c.row_stats = take((int64_t)B * c.P * 2); }
         }
@@ -263,7 +270,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
             if (m->fused) { e.qkvH = take_bf(3 * MH); e.ctxH = take_bf(MH); e.lse = take(LS); }
             else { e.qkv = take(3 * MH); e.P = take(PM); }
             e.ln1_in = take(MH); e.st1 = take((int64_t)m->M * 2);
-            e.fpre = take(MF); e.ln2_in = take(MH); e.st2 = take((int64_t)m->M * 2);
+            e.fpre = take(m->pre16 ? (MF + 1) / 2 : MF); e.ln2_in = take(MH); e.st2 = take((int64_t)m->M * 2);
         }
         m->logits = take((int64_t)m->M * V); m->dlogits = take((int64_t)m->M * V); m->dlogitsH = take_bf((int64_t)m->M * V);
         m->nll = take(B);
@@ -313,9 +320,10 @@ static paa_gemm_desc gdb(const paa_model* m, CBf A, CBf W, float* C, Bf Cb, int 
 // y = x W^T (+bias) (+epilogue): x (M, K) bf16 planes, W [N][K] bf16 planes
 static paa_status linear(const paa_model* m, CBf x, CBf w, const float* bias, float* y, Bf yb, int M, int N, int K,
                          hipStream_t st, const float* residual = nullptr, int act = 0, float* pre = nullptr,
-                         const float* aux = nullptr) {
+                         const float* aux = nullptr, bool x16 = false) {
     paa_gemm_desc d = gdb(m, x, w, y, yb, M, N, K, K, K, N);
     d.bias = bias; d.residual = residual; d.ld_res = N; d.act = act; d.C_pre = pre; d.aux = aux; d.ld_aux = N;
+    d.aux_bf16 = x16 ? 1 : 0;
     return gemm(d, st);
 }
 
@@ -329,7 +337,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         Conv0Args ca{};
         ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
         ca.k = c.k; ca.stride = c.s; ca.w = c.w0; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
-        ca.pre = c.pre; ca.actb = c.actb; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
+        ca.pre = c.pre; ca.pre16 = c.pre16; ca.actb = c.actb; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
         if (a.feat_norm_layer) PAA_TRY(conv0_ln_forward(ca, st)); else PAA_TRY(conv0_gn_forward(ca, m->c0_part, st));
     }
     for (int i = 1; i < nc; ++i) {
@@ -345,7 +353,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             PAA_TRY(layernorm_fwd(c.cv, c.g, c.beta, c.pre, c.row_stats, B * c.P, c.cout, 1e-5f, NOBF, last ? NOBF : c.actb,
                                   last ? c.act_f : nullptr, st));
         } else {
-            d.C_pre = c.pre; d.act = PAA_ACT_GELU;
+            d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.act = PAA_ACT_GELU;
             if (last) d.C = c.act_f; else { d.Cb = c.actb.hi; d.Cb_lo = c.actb.lo; }
             PAA_TRY(gemm(d, st));
         }
@@ -415,7 +423,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         if (!a.stable_ln) {
             PAA_TRY(linear(m, ctxH, e.wo, e.bo, e.ln1_in, NOBF, M, H, H, st, x));                                // r1 = x + attn
             PAA_TRY(layernorm_fwd(e.ln1_in, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));   // y1
-            PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
+            PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre, nullptr, m->pre16));
             PAA_TRY(linear(m, ro(m->factH), e.w2, e.b2, e.ln2_in, NOBF, M, H, F, st, m->xb));                   // r2 = y1 + ffn
             if (lastl) PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, nullptr, e.st2, M, H, a.ln_eps, m->xfinalH, NOBF, nullptr, st));
             else PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, m->xa, e.st2, M, H, a.ln_eps, m->xaH, NOBF, nullptr, st));
@@ -423,7 +431,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         } else {
             PAA_TRY(linear(m, ctxH, e.wo, e.bo, e.ln2_in, NOBF, M, H, H, st, x));                                // r1 = x + attn
             PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, nullptr, e.st2, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));
-            PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre));
+            PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre, nullptr, m->pre16));
             float* xo = lastl ? m->final_in : m->enc[l + 1].ln1_in;
             PAA_TRY(linear(m, ro(m->factH), e.w2, e.b2, xo, NOBF, M, H, F, st, e.ln2_in));                      // r2 = r1 + ffn
             x = xo;
@@ -449,11 +457,11 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
         EncL& e = m->enc[l];
         if (!a.stable_ln) {
             PAA_TRY(layernorm_bwd(dx, e.ln2_in, e.ln2_g, e.st2, nullptr, nullptr, dx, dxH, M, H, st));                  // dr2
-            PAA_TRY(linear(m, ro(dxH), e.w2_t, nullptr, nullptr, m->dfpreH, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
+            PAA_TRY(linear(m, ro(dxH), e.w2_t, nullptr, nullptr, m->dfpreH, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre, m->pre16));
             PAA_TRY(linear(m, ro(m->dfpreH), e.w1_t, nullptr, dx2, NOBF, M, H, F, st, dx));                               // dy1 = dr2 + ...
             PAA_TRY(layernorm_bwd(dx2, e.ln1_in, e.ln1_g, e.st1, nullptr, nullptr, dx2, dx2H, M, H, st));               // dr1
         } else {   // dx = dr2 with its planes in dxH
-            PAA_TRY(linear(m, ro(dxH), e.w2_t, nullptr, nullptr, m->dfpreH, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre));
+            PAA_TRY(linear(m, ro(dxH), e.w2_t, nullptr, nullptr, m->dfpreH, M, F, H, st, nullptr, PAA_ACT_GELU_GRAD, nullptr, e.fpre, m->pre16));
             PAA_TRY(linear(m, ro(m->dfpreH), e.w1_t, nullptr, dx2, NOBF, M, H, F, st));                                   // dn2
             PAA_TRY(layernorm_bwd(dx2, e.ln2_in, e.ln2_g, e.st2, dx, nullptr, dx2, dx2H, M, H, st));                     // dr1 = dr2 + LN2'
         }
@@ -551,7 +559,9 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             paa_gemm_desc d = gdb(m, ro(m->gH[ji]).off(-(int64_t)Q * c.cout), c.wd[rho], nullptr, NOBF, B * c.P, c.cin, K, c.cout, K, ldo);
             if (out_f32) d.C = m->gF[jo] + (int64_t)rho * c.cin;
             else { Bf o = boff(m->gH[jo], (int64_t)rho * c.cin); d.Cb = o.hi; d.Cb_lo = o.lo; }
-            d.act = PAA_ACT_GELU_GRAD; d.aux = pr.pre + (int64_t)rho * c.cin; d.ld_aux = ldo;
+            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0;
+            d.aux = pr.pre16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(pr.pre) + (int64_t)rho * c.cin)
+                             : pr.pre + (int64_t)rho * c.cin;
             PAA_TRY(gemm(d, st));
         }
     }
@@ -638,7 +648,7 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
         const ConvL& c = m->conv[i];
         const std::string b = "conv" + std::to_string(i);
         const int64_t sz = (int64_t)B * c.P * c.cout;
-        if (n == b + ".pre") { p = c.pre; cnt = sz; }
+        if (n == b + ".pre") { if (c.pre16) pb = Bf{reinterpret_cast<unsigned short*>(c.pre), nullptr}; else p = c.pre; cnt = sz; }
         else if (n == b + ".act") { if (c.act_f) p = c.act_f; else pb = c.actb; cnt = sz; }
         else if (n == b + ".cv" && c.cv) { p = c.cv; cnt = sz; }
     }
@@ -648,7 +658,7 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
         if (n == b + ".qkv") { if (e.qkv) p = e.qkv; else pb = e.qkvH; cnt = M * 3 * H; }
         else if (n == b + ".P" && e.P) { p = e.P; cnt = (int64_t)B * a.heads * m->Tp * m->Tp; }
         else if (n == b + ".ln1_in") { p = e.ln1_in; cnt = M * H; }
-        else if (n == b + ".fpre") { p = e.fpre; cnt = M * F; }
+        else if (n == b + ".fpre") { if (m->pre16) pb = Bf{reinterpret_cast<unsigned short*>(e.fpre), nullptr}; else p = e.fpre; cnt = M * F; }
         else if (n == b + ".ln2_in") { p = e.ln2_in; cnt = M * H; }
     }
     if (!p && !pb.hi) {

@@ -32,7 +32,8 @@ struct Conv0Args {
     const float* gamma;      // norm affine
     const float* beta;
     float eps;
-    float* pre;              // (B, P, C) norm output (pre-GELU)
+    float* pre;              // (B, P, C) norm output (pre-GELU); bf16 storage when pre16 (group-norm forward only)
+    int pre16;
     Bf actb;                 // (B, P, C) GELU(pre) as bf16 planes (the next conv's GEMM operand)
     float* gn_stats;         // group: (B, C, 2) mean, rstd over time
     float* gn_bsums;         // group backward: (B, C, 2) mean_t(dy), mean_t(dy * xhat)

@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                 s1 += v; s2 += v * v;
             } else if (MODE == 1) {
                 const float y = (v - mean) * rstd * gam + bet;
-                a.pre[o] = y;
-                store_bf16(a.actb, o, gelu_f(y));
+                if (a.pre16) reinterpret_cast<unsigned short*>(a.pre)[o] = bf16_bits(y); else a.pre[o] = y;
+                store_bf16(a.actb, o, a.pre16 ? gelu_fast(y) : gelu_f(y));
             } else {
                 float dy = bf16_to_f32(a.dpreb.hi[o]);
                 if (a.dpreb.lo) dy += bf16_to_f32(a.dpreb.lo[o]);
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
         for (int t = a.T; t < a.P; ++t)
             for (int c = threadIdx.x; c < a.C; c += 256) {
                 const size_t o = ((size_t)b * a.P + t) * a.C + c;
-                a.pre[o] = 0.f; store_bf16(a.actb, o, 0.f);
+                if (a.pre16) reinterpret_cast<unsigned short*>(a.pre)[o] = 0; else a.pre[o] = 0.f;
+                store_bf16(a.actb, o, 0.f);
             }
 }
 
