@@ -14,6 +14,7 @@
 // so no transposed copy of any tile is ever staged).  Every statistic of an own position (running max / sum, lse,
 // delta) lives in its two lanes (lane, lane^32): no LDS reductions.
 //   forward, dQ : own = queries, other = keys          dK/dV : own = keys, other = queries
+// Exponentials are raw v_exp_f32 (arguments are <= 8 and flush to 0 far below: no denormal-range fix-up needed).
 // Q/K/V/dO are rows of the (M, 3H) / (M, H) bf16 planes the GEMM epilogues write; outputs go back as bf16.
 #include "model_kernels.h"
 
@@ -26,15 +27,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int AT_D = 64;            // head dim
 constexpr int AT_RM = 72;           // row-major tile row stride (bf16): 144 B, conflict-free ds_read_b128
 
-// stage a 32 x 64 tile (rows r0.., valid while < rlim, zero beyond) of a bf16 matrix with row stride ld into a
-// row-major LDS tile [32][AT_RM]; 256 threads, one 16-byte chunk each
-__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ src, int64_t ld, int r0, int rlim,
-                                           unsigned short* rm) {
+// ROWS x 64 tile (rows r0.., valid while < rlim, zero beyond) of a bf16 matrix with row stride ld: global -> registers
+// (256 threads, ROWS / 32 16-byte chunks each), and registers -> row-major LDS tile [ROWS][AT_RM].  Split so the next
+// tile's global loads fly under the current tile's MFMAs.
+template <int ROWS>
+__device__ __forceinline__ void tile_load(const unsigned short* __restrict__ src, int64_t ld, int r0, int rlim,
+                                          uint4 (&v)[ROWS / 32]) {
     const int tid = threadIdx.x;
-    const int row = tid >> 3, ch = tid & 7;
-    uint4 x = make_uint4(0u, 0u, 0u, 0u);
-    if (r0 + row < rlim) x = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + row) * ld + ch * 8);
-    *reinterpret_cast<uint4*>(rm + row * AT_RM + ch * 8) = x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + row < rlim) v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + row) * ld + (tid & 7) * 8);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void tile_store(unsigned short* rm, const uint4 (&v)[ROWS / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) *reinterpret_cast<uint4*>(rm + ((tid >> 3) + 32 * i) * AT_RM + (tid & 7) * 8) = v[i];
 }
 
 // A fragment of k-step s from a row-major tile: lane (lr, lh) -> row lr, elements 16s + 8lh .. +7
@@ -62,6 +73,12 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[16], int s2) {
     for (int j = 0; j < 8; ++j) r[j] = (short)bf16_bits(v[8 * s2 + j]);
     return r;
 }
+__device__ __forceinline__ bf16x8 pack8v(const f32x16& v, int s2) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)bf16_bits(v[8 * s2 + j]);
+    return r;
+}
 // own-position operand fragments (B operand of X = other x own): 16 B at row `own`, k = 16s + 8lh
 __device__ __forceinline__ void load_own(const unsigned short* __restrict__ src, int64_t ld, int row, int lh, bf16x8 (&f)[4]) {
 #pragma unroll
@@ -82,9 +99,12 @@ __device__ __forceinline__ void store_own(unsigned short* __restrict__ dst, int6
 }
 
 // ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sK[32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sV[32 * AT_RM];
+// 64 keys per iteration (two 32-key score tiles), K / V tiles double-buffered in LDS and prefetched through registers:
+// one barrier per 64 keys, 16 MFMAs per wave between barriers.
+__global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnArgs a) {
+    constexpr int KT = 64;
+    __shared__ __attribute__((aligned(16))) unsigned short sK[2][KT * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sV[2][KT * AT_RM];
     const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int q = blockIdx.x * 128 + wave * 32 + lr;
@@ -98,40 +118,74 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     f32x16 o[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
-    const int nt = (a.T + 31) / 32;
+    const int nt = (a.T + KT - 1) / KT;
+    uint4 rk[KT / 32], rv[KT / 32];
+    tile_load<KT>(base + a.H, ld, 0, a.T, rk);
+    tile_load<KT>(base + 2 * a.H, ld, 0, a.T, rv);
+    tile_store<KT>(sK[0], rk);
+    tile_store<KT>(sV[0], rv);
+    __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
-        stage_tile(base + a.H, ld, kt * 32, a.T, sK);
-        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, sV);
-        __syncthreads();
-        f32x16 s;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sK, lr, lh, ks), qf[ks], s, 0, 0, 0);
-        float p[16];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            p[e] = key < a.T ? s[e] * c : -INFINITY;
-            mx = fmaxf(mx, p[e]);
+        const unsigned short* cK = sK[kt & 1];
+        const unsigned short* cV = sV[kt & 1];
+        if (kt + 1 < nt) {
+            tile_load<KT>(base + a.H, ld, (kt + 1) * KT, a.T, rk);
+            tile_load<KT>(base + 2 * a.H, ld, (kt + 1) * KT, a.T, rv);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
+        f32x16 s[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(cK + u * 32 * AT_RM, lr, lh, ks), qf[ks], s[u], 0, 0, 0);
+        }
+        // Online softmax on the raw scores (scale folded into the exponent's FMA).  The running maximum is only
+        // raised — and l, O rescaled — when some row of the wave exceeds it by more than 2^8: exp2 of a bounded
+        // positive excess is harmless in f32 / bf16 and the per-tile rescale of the 32 O registers mostly disappears.
+        float mx = -INFINITY;
+        if (kt + 1 == nt) {                                  // the only tile that can hold keys >= T (zero-filled rows)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * KT + u * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (key >= a.T) s[u][e] = -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[u][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+        if (__any(mx > m + 8.f)) {
+            const float mn = mx > m + 8.f ? mx : m;
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+        }
         float rs = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { p[e] = exp2f(p[e] - mn); rs += p[e]; }
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[u][e] = __builtin_amdgcn_exp2f(fmaf(s[u][e], c, -m)); rs += s[u][e]; }      // s becomes P
         rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        m = mn;
+        l += rs;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pb = pack8(p, s2);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8v(s[u], s2);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sV, lr, lh, dt, s2), pb, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(cV + u * 32 * AT_RM, lr, lh, dt, s2), pb, o[dt], 0, 0, 0);
+            }
+        if (kt + 1 < nt) {
+            tile_store<KT>(sK[(kt + 1) & 1], rk);
+            tile_store<KT>(sV[(kt + 1) & 1], rv);
         }
         __syncthreads();
     }
@@ -143,9 +197,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------- backward: dQ
 // own = queries.  Also computes delta = rowsum(dO * O) and stores it for the dK/dV kernel.
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sK[32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sV[32 * AT_RM];
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sKb[2][32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sVb[2][32 * AT_RM];
     const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int q = blockIdx.x * 128 + wave * 32 + lr;
@@ -171,10 +225,19 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
     const int nt = (a.T + 31) / 32;
+    uint4 rk[1], rv[1];
+    tile_load<32>(base + a.H, ld, 0, a.T, rk);
+    tile_load<32>(base + 2 * a.H, ld, 0, a.T, rv);
+    tile_store<32>(sKb[0], rk);
+    tile_store<32>(sVb[0], rv);
+    __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
-        stage_tile(base + a.H, ld, kt * 32, a.T, sK);
-        stage_tile(base + 2 * a.H, ld, kt * 32, a.T, sV);
-        __syncthreads();
+        const unsigned short* sK = sKb[kt & 1];
+        const unsigned short* sV = sVb[kt & 1];
+        if (kt + 1 < nt) {
+            tile_load<32>(base + a.H, ld, (kt + 1) * 32, a.T, rk);
+            tile_load<32>(base + 2 * a.H, ld, (kt + 1) * 32, a.T, rv);
+        }
         f32x16 s, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -183,12 +246,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sK, lr, lh, ks), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sV, lr, lh, ks), dof[ks], dp, 0, 0, 0);
         }
-        float ds[16];
+        float ds[16];                                        // dS / scale (the scale multiplies dQ once, at the end)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const float p = key < a.T ? exp2f(s[e] * c - lse) : 0.f;
-            ds[e] = p * (dp[e] - delta) * a.scale;
+        for (int e = 0; e < 16; ++e) ds[e] = __builtin_amdgcn_exp2f(fmaf(s[e], c, -lse)) * (dp[e] - delta);
+        if (kt + 1 == nt) {                                  // keys >= T: zero-filled K rows would give p = exp2(-lse)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh >= a.T) ds[e] = 0.f;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -196,17 +260,21 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sK, lr, lh, dt, s2), db, dq[dt], 0, 0, 0);
         }
+        if (kt + 1 < nt) {
+            tile_store<32>(sKb[(kt + 1) & 1], rk);
+            tile_store<32>(sVb[(kt + 1) & 1], rv);
+        }
         __syncthreads();
     }
-    if (q < a.T) store_own(a.dqkv + (int64_t)b * a.P * ld + h * AT_D, ld, q, lh, dq, 1.f);
+    if (q < a.T) store_own(a.dqkv + (int64_t)b * a.P * ld + h * AT_D, ld, q, lh, dq, a.scale);
 }
 
 // ---------------------------------------------------------------------------------- backward: dK, dV
 // own = keys (lanes), other = queries (accumulator rows).
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sQ[32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sdO[32 * AT_RM];
-    __shared__ float sLse[32], sDel[32];
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sQb[2][32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sdOb[2][32 * AT_RM];
+    __shared__ float sLseb[2][32], sDelb[2][32];
     const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const int key = blockIdx.x * 128 + wave * 32 + lr;
@@ -222,15 +290,35 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[0][e] = 0.f; dk[1][e] = 0.f; dv[0][e] = 0.f; dv[1][e] = 0.f; }
     const int nt = (a.T + 31) / 32;
-    for (int qt = 0; qt < nt; ++qt) {
-        stage_tile(base, ld, qt * 32, a.T, sQ);
-        stage_tile(dob, a.H, qt * 32, a.T, sdO);
+    uint4 rq[1], rdo[1];
+    float rl = INFINITY, rd = 0.f;               // lse / delta of query threadIdx.x of the tile (threads 0..31)
+    auto stats_load = [&](int qt) {
         if (threadIdx.x < 32) {
             const int qq = qt * 32 + threadIdx.x;
-            sLse[threadIdx.x] = qq < a.T ? a.lse[(int64_t)bh * a.Tp + qq] : INFINITY;     // exp2(-inf) = 0 for pad queries
-            sDel[threadIdx.x] = qq < a.T ? a.delta[(int64_t)bh * a.Tp + qq] : 0.f;
+            rl = qq < a.T ? a.lse[(int64_t)bh * a.Tp + qq] : INFINITY;     // exp2(-inf) = 0 for pad queries
+            rd = qq < a.T ? a.delta[(int64_t)bh * a.Tp + qq] : 0.f;
         }
-        __syncthreads();
+    };
+    auto stats_store = [&](int buf) {
+        if (threadIdx.x < 32) { sLseb[buf][threadIdx.x] = rl; sDelb[buf][threadIdx.x] = rd; }
+    };
+    tile_load<32>(base, ld, 0, a.T, rq);
+    tile_load<32>(dob, a.H, 0, a.T, rdo);
+    stats_load(0);
+    tile_store<32>(sQb[0], rq);
+    tile_store<32>(sdOb[0], rdo);
+    stats_store(0);
+    __syncthreads();
+    for (int qt = 0; qt < nt; ++qt) {
+        const unsigned short* sQ = sQb[qt & 1];
+        const unsigned short* sdO = sdOb[qt & 1];
+        const float* sLse = sLseb[qt & 1];
+        const float* sDel = sDelb[qt & 1];
+        if (qt + 1 < nt) {
+            tile_load<32>(base, ld, (qt + 1) * 32, a.T, rq);
+            tile_load<32>(dob, a.H, (qt + 1) * 32, a.T, rdo);
+            stats_load(qt + 1);
+        }
         f32x16 s, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -243,8 +331,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
-            p[e] = exp2f(s[e] * c - sLse[r]);
-            ds[e] = p[e] * (dp[e] - sDel[r]) * a.scale;
+            p[e] = __builtin_amdgcn_exp2f(fmaf(s[e], c, -sLse[r]));
+            ds[e] = p[e] * (dp[e] - sDel[r]);                // dS / scale (applied to dK at the end)
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -255,11 +343,16 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnArgs a) {
                 dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sQ, lr, lh, dt, s2), db, dk[dt], 0, 0, 0);
             }
         }
+        if (qt + 1 < nt) {
+            tile_store<32>(sQb[(qt + 1) & 1], rq);
+            tile_store<32>(sdOb[(qt + 1) & 1], rdo);
+            stats_store((qt + 1) & 1);
+        }
         __syncthreads();
     }
     if (key < a.T) {
         unsigned short* o = a.dqkv + (int64_t)b * a.P * ld + h * AT_D;
-        store_own(o + a.H, ld, key, lh, dk, 1.f);
+        store_own(o + a.H, ld, key, lh, dk, a.scale);
         store_own(o + 2 * a.H, ld, key, lh, dv, 1.f);
     }
 }
