@@ -697,10 +697,301 @@ __global__ __launch_bounds__(512) void k_ctc(const float* __restrict__ logits, c
     }
 }
 
-// work size in FLOATS per clip (the kernel stores doubles): lp [T][V] + alpha, beta [T][2S+1]
+// ---- wave-synchronous CTC (label capacity 2 S_max + 1 <= 1024) ----------------------------------------------------------
+// The recursions run in the PROBABILITY domain in float64 with exact power-of-two rescaling instead of the log domain:
+// no exp / log inside the time loop, and no workgroup barrier either — one wave runs alpha forwards, a second wave runs
+// beta backwards, each lane owning NS consecutive states of the extended label sequence in registers; a step needs the
+// two boundary states of the neighbouring lane (shuffles) and the emission probabilities y_t(l_s) (gathered from the
+// frame's softmax row, staged one step ahead).  After every step the row is scaled by 2^-E, E = the largest binary
+// exponent in the row (integer wave maximum through DPP): scaling by powers of two is exact, so the schedule cannot
+// change a single bit of the result, and the cumulative exponents EA_t / EB_t are integers.
+//   log P = log(ahat_{T-1}(S'-1) + ahat_{T-1}(S'-2)) + EA_{T-1} ln 2
+//   gamma_t(s) = ahat_t(s) bhat_t(s) / y_t(l_s) * 2^(EA_t + EB_t - EA_{T-1}) / Phat        (posterior occupancy)
+// so the gradient phase needs no reduction either: one wave per frame, fixed-point LDS atomics per class (order
+// independent => bitwise reproducible), dlogits[t][c] = scale * (y_t(c) - sum_{s: l_s = c} gamma_t(s)).
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));    // row_mirror
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// Per-clip work layout (floats): y [T][V] | ahat [T][64 NS] f64 | bhat [T][64 NS] f64 | EA [T] i32 | EB [T] i32 |
+// lab [64 NS] i32 (lab[j * 64 + lane] = label of state lane * NS + j, -1 past the end) | Phat f64, EA_{T-1} i32, S' i32
+struct CtcWork {
+    float* y; double* arow; double* brow; int* ea; int* eb; int* lab; double* phat; int* tail;
+};
+__device__ __forceinline__ CtcWork ctc_work(float* wk, int T, int V, int row) {
+    CtcWork w;
+    w.y = wk;
+    w.arow = reinterpret_cast<double*>(wk + (((size_t)T * V + 1) & ~(size_t)1));
+    w.brow = w.arow + (size_t)T * row;
+    w.ea = reinterpret_cast<int*>(w.brow + (size_t)T * row);
+    w.eb = w.ea + ((T + 1) & ~1);
+    w.lab = w.eb + ((T + 1) & ~1);
+    w.phat = reinterpret_cast<double*>(w.lab + row);
+    w.tail = reinterpret_cast<int*>(w.phat + 1);
+    return w;
+}
+
+// softmax of every frame of every clip: 32 lanes per frame, 8 frames per workgroup
+__global__ __launch_bounds__(256) void k_ctc_softmax(const float* __restrict__ logits, int B, int T, int Tpad, int V,
+                                                     float* __restrict__ work, int64_t wpc) {
+    const int f = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (f >= B * T) return;
+    const int b = f / T, t = f - b * T, c = threadIdx.x & 31;
+    const float* lg = logits + ((size_t)b * Tpad + t) * V;
+    float* y = work + (size_t)b * wpc + (size_t)t * V;
+    float mx = -INFINITY;
+    for (int cc = c; cc < V; cc += 32) mx = fmaxf(mx, lg[cc]);
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
+    float se = 0.f;
+    for (int cc = c; cc < V; cc += 32) se += __expf(lg[cc] - mx);
+    for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 32);
+    const float inv = 1.0f / se;
+    for (int cc = c; cc < V; cc += 32) y[cc] = __expf(lg[cc] - mx) * inv;
+}
+
+// the two recursions of one clip: wave 0 alpha, wave 1 beta; LDS_TAB: the clip's y table is first copied to LDS
+// whole-wave shift by one lane through DPP (gfx9 wave_shr / wave_shl): lane i receives lane i-1 (i+1); the first (last)
+// lane receives 0.  A few cycles instead of the ~120-cycle LDS round trip of ds_bpermute, on the serial chain of a step.
+__device__ __forceinline__ double wave_shr1(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NS, bool LDS_TAB>
+__global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ labels, int T, int V, int S_max, int blank,
+                                                 float* __restrict__ nll_out, float* __restrict__ work, int64_t wpc) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int SPmax = 2 * S_max + 1;
+    constexpr int ROW = 64 * NS;
+    const CtcWork w = ctc_work(work + (size_t)b * wpc, T, V, ROW);
+    int* lab = reinterpret_cast<int*>(smf + (LDS_TAB ? (((size_t)T * V + 3) & ~(size_t)3) : 0));      // [SPmax] extended labels
+    __shared__ int s_len;
+    __shared__ double s_pend[2];
+    // extended labels: valid labels are the non-negative entries, in order (HF masked_select).  The label row is first
+    // copied to LDS by all threads (one global round trip instead of S_max dependent ones), then compacted by thread 0.
+    int* raw = lab + SPmax;                                       // [S_max]
+    for (int s = tid; s < S_max; s += 128) raw[s] = labels[(size_t)b * S_max + s];
+    if (LDS_TAB) {          // y table -> LDS, 8 independent 16-byte loads in flight per thread
+        const int n4 = T * V / 4;
+        const float4* src = reinterpret_cast<const float4*>(w.y);
+        float4* dst = reinterpret_cast<float4*>(smf);
+        for (int i0 = 0; i0 < n4; i0 += 128 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 128 + tid; if (i < n4) v[u] = src[i]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 128 + tid; if (i < n4) dst[i] = v[u]; }
+        }
+        for (int i = n4 * 4 + tid; i < T * V; i += 128) smf[i] = w.y[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int k = 0;
+        lab[0] = blank;
+        for (int s = 0; s < S_max; ++s) {
+            const int v = raw[s];
+            if (v >= 0) { lab[2 * k + 1] = v; lab[2 * k + 2] = blank; ++k; }
+        }
+        s_len = k;
+        s_pend[0] = 0.0; s_pend[1] = 0.0;
+    }
+    const float* ytab = LDS_TAB ? smf : w.y;
+    __syncthreads();
+    const int S = s_len, SP = 2 * S + 1;
+    int l[NS];
+    unsigned skf = 0, skb = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int s = lane * NS + j;
+        l[j] = s < SP ? lab[s] : blank;
+        if (s < SP && s >= 2 && l[j] != blank && l[j] != lab[s - 2]) skf |= 1u << j;
+        if (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l[j]) skb |= 1u << j;
+        if (wave == 0) w.lab[j * 64 + lane] = s < SP ? l[j] : -1;
+    }
+    const bool fwd = wave == 0;
+    double* rows = fwd ? w.arow : w.brow;
+    int* ecc = fwd ? w.ea : w.eb;
+    double a[NS];
+    float em[NS], emn[NS];
+    int esum = 0;
+    auto emis = [&](int t, float (&e)[NS]) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) e[j] = (lane * NS + j < SP) ? ytab[(size_t)t * V + l[j]] : 0.f;
+    };
+    // exact power-of-two normalisation (every 4th step: a step shrinks a row by at most 2^-149, far inside the f64
+    // exponent range over 4 steps), then store the row and the exponent it is scaled by
+    auto finish_row = [&](int t, bool norm) {
+        if (norm) {
+            double mx = a[0];
+#pragma unroll
+            for (int j = 1; j < NS; ++j) mx = fmax(mx, a[j]);
+            const int e = wave_max_i32(mx > 0.0 ? __builtin_amdgcn_frexp_exp(mx) : -100000);
+            if (e > -100000) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) a[j] = __builtin_amdgcn_ldexp(a[j], -e);
+                esum += e;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) rows[(size_t)t * ROW + j * 64 + lane] = a[j];
+        if (lane == 0) ecc[t] = esum;
+    };
+    const int t0 = fwd ? 0 : T - 1;
+    emis(t0, em);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int s = lane * NS + j;
+        const bool on = fwd ? (s == 0 || s == 1) : (s == SP - 1 || s == SP - 2);
+        a[j] = (on && s < SP) ? (double)em[j] : 0.0;
+    }
+    finish_row(t0, true);
+    if (T > 1) emis(fwd ? 1 : T - 2, em);
+    for (int i = 1; i < T; ++i) {
+        const int t = fwd ? i : T - 1 - i;
+        if (i + 1 < T) emis(fwd ? i + 1 : T - 2 - i, emn);      // next step's emissions fly under this step
+        double n1, n2;                                          // the neighbour lane's two boundary states
+        if (fwd) {
+            n1 = wave_shr1(a[NS - 1]);
+            n2 = NS >= 2 ? wave_shr1(a[NS >= 2 ? NS - 2 : 0]) : wave_shr1(n1);
+        } else {
+            n1 = wave_shl1(a[0]);
+            n2 = NS >= 2 ? wave_shl1(a[NS >= 2 ? 1 : 0]) : wave_shl1(n1);
+        }
+        double nw[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double v = a[j];
+            if (fwd) {
+                v += j >= 1 ? a[j >= 1 ? j - 1 : 0] : n1;
+                const double v2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? n1 : n2);
+                if (skf & (1u << j)) v += v2;
+            } else {
+                v += j + 1 < NS ? a[j + 1 < NS ? j + 1 : 0] : n1;
+                const double v2 = j + 2 < NS ? a[j + 2 < NS ? j + 2 : 0] : (j + 2 == NS ? n1 : n2);
+                if (skb & (1u << j)) v += v2;
+            }
+            nw[j] = v * (double)em[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { a[j] = nw[j]; em[j] = emn[j]; }
+        finish_row(t, (i & 3) == 0);
+    }
+    if (fwd) {           // Phat = ahat_{T-1}(S'-1) + ahat_{T-1}(S'-2)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int s = lane * NS + j;
+            if (s == SP - 1) s_pend[0] = a[j];
+            if (s == SP - 2) s_pend[1] = a[j];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double phat = s_pend[0] + s_pend[1];
+        *w.phat = phat;
+        w.tail[0] = esum;                 // thread 0 is lane 0 of the alpha wave: EA_{T-1}
+        w.tail[1] = SP;
+        nll_out[b] = phat > 0.0 ? (float)(-(log(phat) + (double)esum * 0.69314718055994530942)) : INFINITY;
+    }
+}
+
+// gradient rows: one wave per frame (grid: frames / 4 x clips)
+template <int NS>
+__global__ __launch_bounds__(256) void k_ctc_grad(int T, int Tpad, int V, float gscale, float* __restrict__ dlogits, Bf dlb,
+                                                  float* __restrict__ work, int64_t wpc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned occs[];     // [4][V]
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wave;
+    constexpr int ROW = 64 * NS;
+    const CtcWork w = ctc_work(work + (size_t)b * wpc, T, V, ROW);
+    float* dl = dlogits + (size_t)b * Tpad * V;
+    const size_t dlo = (size_t)b * Tpad * V;
+    if (t >= T) {                         // pad frames [T, Tpad): zero gradient
+        if (t < Tpad) for (int c = lane; c < V; c += 64) { dl[(size_t)t * V + c] = 0.f; store_bf16(dlb, dlo + (size_t)t * V + c, 0.f); }
+        return;
+    }
+    const double phat = *w.phat;
+    if (!(phat > 0.0)) {                  // infeasible alignment: zero_infinity=False propagates non-finite gradients
+        for (int c = lane; c < V; c += 64) { dl[(size_t)t * V + c] = NAN; store_bf16(dlb, dlo + (size_t)t * V + c, NAN); }
+        return;
+    }
+    const int sh = w.ea[t] + w.eb[t] - w.tail[0];
+    const double invp = 1.0 / phat;
+    unsigned* wocc = occs + wave * V;
+    for (int c = lane; c < V; c += 64) wocc[c] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const float* y = w.y + (size_t)t * V;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int lj = w.lab[j * 64 + lane];
+        if (lj >= 0) {
+            const float yv = y[lj];
+            const double ab = __builtin_amdgcn_ldexp(w.arow[(size_t)t * ROW + j * 64 + lane], sh / 2) *
+                              __builtin_amdgcn_ldexp(w.brow[(size_t)t * ROW + j * 64 + lane], sh - sh / 2);
+            const float g = yv > 0.f ? (float)(ab * invp) * __builtin_amdgcn_rcpf(yv) : 0.f;
+            const unsigned q = (unsigned)(fminf(g, 2.f) * 1073741824.f + 0.5f);
+            if (q) atomicAdd(&wocc[lj], q);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // this wave's LDS atomics before its reads below
+    for (int c = lane; c < V; c += 64) {
+        const float gv = gscale * (y[c] - (float)wocc[c] * (1.f / 1073741824.f));
+        dl[(size_t)t * V + c] = gv;
+        store_bf16(dlb, dlo + (size_t)t * V + c, gv);
+    }
+}
+
+template <int NS>
+static paa_status launch_ctc_ws(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
+                                float gscale, float* nll, float* dlogits, Bf dlb, float* work, int64_t wpc, hipStream_t st) {
+    const int SPmax = 2 * S_max + 1;
+    hipLaunchKernelGGL(k_ctc_softmax, dim3(cdiv((int64_t)B * T, 8)), dim3(256), 0, st, logits, B, T, Tpad, V, work, wpc);
+    PAA_LAUNCH_CHECK();
+    const size_t tab = sizeof(float) * (((size_t)T * V + 3) & ~(size_t)3);
+    const size_t small = sizeof(int) * ((size_t)SPmax + S_max) + 64;
+    const bool lds_tab = tab + small <= 150 * 1024;
+    const size_t lds = small + (lds_tab ? tab : 0);
+    if (lds_tab) {
+        static bool attr = false;
+        if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctc_rec<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; }
+        hipLaunchKernelGGL((k_ctc_rec<NS, true>), dim3(B), dim3(128), lds, st, labels, T, V, S_max, blank, nll, work, wpc);
+    } else {
+        hipLaunchKernelGGL((k_ctc_rec<NS, false>), dim3(B), dim3(128), lds, st, labels, T, V, S_max, blank, nll, work, wpc);
+    }
+    PAA_LAUNCH_CHECK();
+    if (dlogits) {
+        hipLaunchKernelGGL((k_ctc_grad<NS>), dim3(cdiv(Tpad, 4), B), dim3(256), sizeof(unsigned) * 4 * V, st, T, Tpad, V, gscale, dlogits, dlb, work, wpc);
+        PAA_LAUNCH_CHECK();
+    }
+    return PAA_OK;
+}
+
 int conv0_chunks(int T) { return cdiv(T, C0_TCH); }
 
-int64_t ctc_work_floats_per_clip(int T, int V, int S_max) { return 2 * ((int64_t)T * V + 2 * (int64_t)T * (2 * S_max + 1)); }
+// states per lane of the wave-synchronous kernel for a label capacity (0: use the log-domain kernel)
+static int ctc_ws_ns(int SPmax) {
+    const int ns = cdiv(SPmax, 64);
+    return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 16 ? 16 : 0;
+}
+// work size in floats per clip — log-domain kernel: lp [T][V] + alpha, beta [T][2S+1] doubles;
+// wave-synchronous kernels: see CtcWork
+int64_t ctc_work_floats_per_clip(int T, int V, int S_max) {
+    const int64_t SPmax = 2 * (int64_t)S_max + 1;
+    const int ns = ctc_ws_ns((int)SPmax);
+    if (ns == 0) return 2 * ((int64_t)T * V + 2 * (int64_t)T * SPmax);
+    return (((int64_t)T * V + 1) & ~(int64_t)1) + 4 * (int64_t)T * 64 * ns + 2 * (((int64_t)T + 1) & ~(int64_t)1) + 64 * ns + 16;
+}
 
 paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
                float grad_scale, float* nll, float* dlogits, Bf dlb, float* work, hipStream_t st) {
@@ -708,10 +999,17 @@ paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpa
     if (V > 256) PAA_FAIL(PAA_ERR_SIZE, "ctc: vocab %d > 256", V);
     if ((uintptr_t)work & 7) PAA_FAIL(PAA_ERR_ARG, "ctc: work buffer must be 8-byte aligned");
     const int SPmax = 2 * S_max + 1;
+    const int64_t wpc = ctc_work_floats_per_clip(T, V, S_max);
+    const int ns = ctc_ws_ns(SPmax);
+    if (ns) {                         // wave-synchronous kernel: ns states per lane
+#define PAA_CTC_WS(N) case N: return launch_ctc_ws<N>(logits, labels, B, T, Tpad, V, S_max, blank, grad_scale, nll, dlogits, dlb, work, wpc, st)
+        switch (ns) { PAA_CTC_WS(1); PAA_CTC_WS(2); PAA_CTC_WS(4); PAA_CTC_WS(6); PAA_CTC_WS(8); PAA_CTC_WS(16); }
+#undef PAA_CTC_WS
+    }
     const size_t lds = sizeof(double) * 4 * (size_t)SPmax + sizeof(int) * ((size_t)SPmax + 8 * V);
     if (lds > 160 * 1024) PAA_FAIL(PAA_ERR_SIZE, "ctc: label capacity %d needs %zu bytes of LDS", S_max, lds);
     hipLaunchKernelGGL(k_ctc, dim3(B), dim3(512), lds, st, logits, labels, T, Tpad, V, S_max, blank, grad_scale, nll,
-                       dlogits, work, ctc_work_floats_per_clip(T, V, S_max) / 2, dlb);
+                       dlogits, work, wpc / 2, dlb);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
