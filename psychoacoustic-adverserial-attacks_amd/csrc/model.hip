@@ -244,7 +244,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         }
         const ConvL& c0 = m->conv[0];
         m->gn_stats = take((int64_t)B * c0.cout * 2); m->gn_bsums = take((int64_t)B * c0.cout * 2);
-        m->c0_part = take((int64_t)B * conv0_chunks(c0.T) * c0.cout * 2);
+        m->c0_part = take(conv0_part_floats(B, c0.T, c0.cout));
         if (a.feat_norm_layer) m->G = take((int64_t)B * c0.P * c0.k);
         else {
             m->G1 = take((int64_t)B * c0.P * 16); m->c0_Mx = take((int64_t)B * c0.k * c0.k); m->c0_kc = take((int64_t)B * 16);

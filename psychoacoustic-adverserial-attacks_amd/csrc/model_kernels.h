@@ -53,6 +53,7 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
 int conv0_chunks(int T);
 
 int64_t ctc_work_floats_per_clip(int T, int V, int S_max);
+int64_t conv0_part_floats(int B, int T, int C);
 paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
                float grad_scale, float* nll, float* dlogits, Bf dlb, float* work, hipStream_t st);
 paa_status sum_small(const float* x, int n, float* out, hipStream_t st);

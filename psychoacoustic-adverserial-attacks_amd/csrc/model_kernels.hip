@@ -222,6 +222,75 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
             }
 }
 
+// GroupNorm statistics of conv0 WITHOUT a pass over the (T, C) output.  With one input channel the output of channel
+// c at frame t is w_c . x_t (x_t = the k input samples of the frame), so over a clip
+//   sum_t v = w_c . Sx,   sum_t v^2 = w_c^T Gx w_c,   Sx = sum_t x_t,  Gx = sum_t x_t x_t^T   (k x k, per clip)
+// k_conv0_gram accumulates the 55 + 10 distinct entries per chunk of frames (f32 products of <= 8 frames per thread,
+// summed in f64, fixed order => reproducible); k_conv0_gn_stats reduces the chunks and evaluates the two quadratic
+// forms per channel in f64.
+constexpr int C0_GCH = 2048;       // frames per workgroup of the Gram kernel
+constexpr int C0_GQ = 66;          // 55 lower-triangle products + 10 sums (+1 pad)
+__global__ __launch_bounds__(256) void k_conv0_gram(Conv0Args a, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    __shared__ double red[256 / 64];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * C0_GCH;
+    const int nt = min(C0_GCH, a.T - t0);
+    const int span = (nt - 1) * a.stride + a.k;
+    for (int i = threadIdx.x; i < span; i += 256) xs[i] = in_sample(a, b, t0 * a.stride + i);
+    __syncthreads();
+    float acc[65];
+#pragma unroll
+    for (int q = 0; q < 65; ++q) acc[q] = 0.f;
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        float xw[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xw[j] = j < a.k ? xs[t * a.stride + j] : 0.f;
+        int idx = 0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+#pragma unroll
+            for (int q = 0; q <= j; ++q) acc[idx++] += xw[j] * xw[q];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[55 + j] += xw[j];
+    }
+    double* out = part + ((size_t)b * gridDim.x + chunk) * C0_GQ;
+#pragma unroll
+    for (int q = 0; q < 65; ++q) {
+        const double t = block_sum<double, 256>((double)acc[q], red);
+        if (threadIdx.x == 0) out[q] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_conv0_gn_stats(Conv0Args a, const double* __restrict__ part, int nchunk) {
+    __shared__ double G[C0_GQ];
+    const int b = blockIdx.x;
+    if (threadIdx.x < 65) {
+        double t = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) t += part[((size_t)b * nchunk + ch) * C0_GQ + threadIdx.x];
+        G[threadIdx.x] = t;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        double w[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[j] = j < a.k ? (double)a.w[c * a.k + j] : 0.0;
+        double s1 = 0.0, s2 = 0.0;
+        int idx = 0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+#pragma unroll
+            for (int q = 0; q <= j; ++q) { s2 += (q == j ? 1.0 : 2.0) * w[j] * w[q] * G[idx]; ++idx; }
+            s1 += w[j] * G[55 + j];
+        }
+        const double mean = s1 / a.T;
+        double var = s2 / a.T - mean * mean;
+        if (var < 0.0) var = 0.0;
+        a.gn_stats[((size_t)b * a.C + c) * 2] = (float)mean;
+        a.gn_stats[((size_t)b * a.C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+}
+
 // Reduce the per-chunk partials in f64.  MODE 0: (sum, sumsq) -> (mean, rstd);  MODE 2: -> (s1/n, s2/n)
 __global__ __launch_bounds__(256) void k_conv0_gn_finalize(const float* __restrict__ part, float* __restrict__ out,
                                                           int B, int C, int nchunk, int n, float eps, int mode) {
@@ -472,11 +541,14 @@ paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st) {
     const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10);
     Conv0Args b = a;
     b.part = part;
-    hipLaunchKernelGGL(k_conv0_gn<0>, dim3(nchunk, a.B), dim3(256), lds, st, b);
-    PAA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 64)), dim3(256), 0, st, (const float*)part,
-                       (float*)a.gn_stats, a.B, a.C, nchunk, a.T, a.eps, 0);
-    PAA_LAUNCH_CHECK();
+    {   // statistics from the k x k input Gram matrix of each clip (no pass over the conv output)
+        const int ng = cdiv(a.T, C0_GCH);
+        double* gp = reinterpret_cast<double*>(part);
+        hipLaunchKernelGGL(k_conv0_gram, dim3(ng, a.B), dim3(256), sizeof(float) * ((C0_GCH - 1) * a.stride + 10), st, b, gp);
+        PAA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_conv0_gn_stats, dim3(a.B), dim3(256), 0, st, b, (const double*)gp, ng);
+        PAA_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_conv0_gn<1>, dim3(nchunk, a.B), dim3(256), lds, st, b);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
@@ -978,6 +1050,10 @@ static paa_status launch_ctc_ws(const float* logits, const int32_t* labels, int 
 }
 
 int conv0_chunks(int T) { return cdiv(T, C0_TCH); }
+// floats of the conv0 partial-sum workspace: per-chunk channel partials (backward) or Gram partials in f64 (forward)
+int64_t conv0_part_floats(int B, int T, int C) {
+    return std::max((int64_t)B * cdiv(T, C0_TCH) * C * 2, (int64_t)B * cdiv(T, C0_GCH) * C0_GQ * 2) + 64;
+}
 
 // states per lane of the wave-synchronous kernel for a label capacity (0: use the log-domain kernel)
 static int ctc_ws_ns(int SPmax) {
