@@ -166,7 +166,6 @@ __device__ __forceinline__ float in_sample(const Conv0Args& a, int b, int i) {
 constexpr int C0_TCH = 64;   // frames per workgroup in the channel-per-thread kernels
 
 // Channel-per-thread mapping (thread owns channels tid, tid+256, ...; loops over a chunk of frames).
-// MODE 0: GroupNorm statistics partials (sum v, sum v^2)           -> part[b][chunk][c][2]
 // MODE 1: apply GroupNorm + GELU                                    -> pre[b][t][c], act[b][t][c]
 // MODE 2: backward statistics partials (sum dy, sum dy*xhat)        -> part[b][chunk][c][2]
 template <int MODE>
@@ -176,40 +175,101 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
     const int t0 = chunk * C0_TCH;
     const int nt = min(C0_TCH, a.T - t0);
     const int span = (nt - 1) * a.stride + a.k;
-    const int span_alloc = (C0_TCH - 1) * a.stride + 10;
+    const int span_alloc = (C0_TCH - 1) * a.stride + 10 + 8;
     for (int i = threadIdx.x; i < span_alloc; i += 256) xs[i] = (i < span) ? in_sample(a, b, t0 * a.stride + i) : 0.f;
     __syncthreads();
-    for (int c = threadIdx.x; c < a.C; c += 256) {
-        float w[10];
+    // wav2vec2's conv0 (k = 10, stride 5, even C): a thread owns a channel PAIR (4-byte bf16x2 accesses instead of
+    // 2-byte ones) and walks the frames 4 at a time — the 4 windows come from 7 broadcast ds_read_b128 and, in the
+    // backward pass, the 4 gradient loads are issued together so that enough bytes are in flight to cover HBM latency.
+    if (a.stride == 5 && a.k == 10 && (a.C & 1) == 0) {
+        for (int c = 2 * threadIdx.x; c < a.C; c += 512) {
+            float w[2][10], mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f}, gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
+            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 10; ++j) w[j] = (j < a.k) ? a.w[c * a.k + j] : 0.f;
-        float mean = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
-        if (MODE >= 1) {
-            mean = a.gn_stats[((size_t)b * a.C + c) * 2];
-            rstd = a.gn_stats[((size_t)b * a.C + c) * 2 + 1];
-            gam = a.gamma[c]; bet = a.beta[c];
-        }
-        float s1 = 0.f, s2 = 0.f;
-        for (int t = 0; t < nt; ++t) {
-            float v = 0.f;
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v += w[j] * xs[t * a.stride + j];
-            const size_t o = ((size_t)b * a.P + t0 + t) * a.C + c;
-            if (MODE == 0) {
-                s1 += v; s2 += v * v;
-            } else if (MODE == 1) {
-                const float y = (v - mean) * rstd * gam + bet;
-                if (a.pre16) reinterpret_cast<unsigned short*>(a.pre)[o] = bf16_bits(y); else a.pre[o] = y;
-                store_bf16(a.actb, o, a.pre16 ? gelu_fast(y) : gelu_f(y));
-            } else {
-                float dy = bf16_to_f32(a.dpreb.hi[o]);
-                if (a.dpreb.lo) dy += bf16_to_f32(a.dpreb.lo[o]);
-                s1 += dy; s2 += dy * ((v - mean) * rstd);
+                for (int j = 0; j < 10; ++j) w[h][j] = a.w[(c + h) * 10 + j];
+                mean[h] = a.gn_stats[((size_t)b * a.C + c + h) * 2];
+                rstd[h] = a.gn_stats[((size_t)b * a.C + c + h) * 2 + 1];
+                gam[h] = a.gamma[c + h]; bet[h] = a.beta[c + h];
+            }
+            for (int t = 0; t < nt; t += 4) {
+                unsigned dh[4] = {0u, 0u, 0u, 0u}, dl4[4] = {0u, 0u, 0u, 0u};
+                if (MODE == 2) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        if (t + f < nt) {
+                            const size_t o = ((size_t)b * a.P + t0 + t + f) * a.C + c;
+                            dh[f] = *reinterpret_cast<const unsigned*>(a.dpreb.hi + o);
+                            if (a.dpreb.lo) dl4[f] = *reinterpret_cast<const unsigned*>(a.dpreb.lo + o);
+                        }
+                }
+                float xw[28];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(xs + t * 5 + 4 * q);
+                    xw[4 * q] = x4.x; xw[4 * q + 1] = x4.y; xw[4 * q + 2] = x4.z; xw[4 * q + 3] = x4.w;
+                }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    if (t + f >= nt) continue;
+                    const size_t o = ((size_t)b * a.P + t0 + t + f) * a.C + c;
+                    float v[2] = {0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) { v[0] += w[0][j] * xw[5 * f + j]; v[1] += w[1][j] * xw[5 * f + j]; }
+                    if (MODE == 1) {
+                        float y[2], g[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            y[h] = (v[h] - mean[h]) * rstd[h] * gam[h] + bet[h];
+                            g[h] = a.pre16 ? gelu_fast(y[h]) : gelu_f(y[h]);
+                        }
+                        if (a.pre16) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(a.pre) + o) = bf16_bits(y[0]) | ((unsigned)bf16_bits(y[1]) << 16);
+                        else *reinterpret_cast<float2*>(a.pre + o) = make_float2(y[0], y[1]);
+                        const unsigned short h0 = bf16_bits(g[0]), h1 = bf16_bits(g[1]);
+                        *reinterpret_cast<unsigned*>(a.actb.hi + o) = h0 | ((unsigned)h1 << 16);
+                        if (a.actb.lo)
+                            *reinterpret_cast<unsigned*>(a.actb.lo + o) = bf16_bits(g[0] - bf16_to_f32(h0)) | ((unsigned)bf16_bits(g[1] - bf16_to_f32(h1)) << 16);
+                    } else {
+                        const float dy0 = __uint_as_float(dh[f] << 16) + __uint_as_float(dl4[f] << 16);
+                        const float dy1 = __uint_as_float(dh[f] & 0xFFFF0000u) + __uint_as_float(dl4[f] & 0xFFFF0000u);
+                        s1[0] += dy0; s2[0] += dy0 * ((v[0] - mean[0]) * rstd[0]);
+                        s1[1] += dy1; s2[1] += dy1 * ((v[1] - mean[1]) * rstd[1]);
+                    }
+                }
+            }
+            if (MODE != 1) {
+                const size_t o = (((size_t)b * gridDim.x + chunk) * a.C + c) * 2;
+                *reinterpret_cast<float4*>(a.part + o) = make_float4(s1[0], s2[0], s1[1], s2[1]);
             }
         }
-        if (MODE != 1) {
-            const size_t o = (((size_t)b * gridDim.x + chunk) * a.C + c) * 2;
-            a.part[o] = s1; a.part[o + 1] = s2;
+    } else {
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            float w[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[j] = (j < a.k) ? a.w[c * a.k + j] : 0.f;
+            const float mean = a.gn_stats[((size_t)b * a.C + c) * 2], rstd = a.gn_stats[((size_t)b * a.C + c) * 2 + 1];
+            const float gam = a.gamma[c], bet = a.beta[c];
+            float s1 = 0.f, s2 = 0.f;
+            for (int t = 0; t < nt; ++t) {
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v += w[j] * xs[t * a.stride + j];
+                const size_t o = ((size_t)b * a.P + t0 + t) * a.C + c;
+                if (MODE == 1) {
+                    const float y = (v - mean) * rstd * gam + bet;
+                    if (a.pre16) reinterpret_cast<unsigned short*>(a.pre)[o] = bf16_bits(y); else a.pre[o] = y;
+                    store_bf16(a.actb, o, a.pre16 ? gelu_fast(y) : gelu_f(y));
+                } else {
+                    float dy = bf16_to_f32(a.dpreb.hi[o]);
+                    if (a.dpreb.lo) dy += bf16_to_f32(a.dpreb.lo[o]);
+                    s1 += dy; s2 += dy * ((v - mean) * rstd);
+                }
+            }
+            if (MODE != 1) {
+                const size_t o = (((size_t)b * gridDim.x + chunk) * a.C + c) * 2;
+                a.part[o] = s1; a.part[o + 1] = s2;
+            }
         }
     }
     // pad rows [T, P) of this clip are zero
@@ -538,7 +598,7 @@ __global__ void k_input_grad_gn(Conv0Args a, float* __restrict__ grad) {
 paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st) {
     if (a.k > 10 || a.C > 4096) PAA_FAIL(PAA_ERR_ARG, "conv0: kernel %d / channels %d unsupported", a.k, a.C);
     const int nchunk = cdiv(a.T, C0_TCH);
-    const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10);
+    const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10 + 8);
     Conv0Args b = a;
     b.part = part;
     {   // statistics from the k x k input Gram matrix of each clip (no pass over the conv output)
@@ -571,7 +631,7 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
         return PAA_OK;
     }
     const int nchunk = cdiv(a.T, C0_TCH);
-    const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10);
+    const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10 + 8);
     Conv0Args b = a;
     b.part = part;
     hipLaunchKernelGGL(k_conv0_gn<2>, dim3(nchunk, a.B), dim3(256), lds, st, b);     // s1 = mean_t dy, s2 = mean_t dy*xhat
