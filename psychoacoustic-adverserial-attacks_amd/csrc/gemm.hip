@@ -694,6 +694,111 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     }
 }
 
+// ---- grouped positional convolution: windowed A, slab in LDS ------------------------------------------------------------
+// C[z][m][n] = sum_{tap} sum_{ci < KS} A_z[m + tap - pad][ci] * B_z2[n][tap * KS + ci], rows outside [0, a_rows_valid) zero
+// (a_window products with a_kseg = KS in {48, 64}, N <= 64: wav2vec2's 128-tap grouped conv and its dgrad).  Through
+// the general loader every K tile re-reads its shifted A rows from L2 — ~100 times per output tile; here the
+// 128 + taps - 1 input rows a 128-row output tile touches are loaded ONCE into an LDS slab and every tap reads its
+// shifted 32-row window of it (row stride KS + 8 bf16: conflict-free ds_read_b128).  The weights stream through a
+// register-prefetched LDS stage of TB = 4 taps.  4 waves, 32 output rows x 64 (N padded) columns each.
+template <int PREC, int KS>
+__global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
+    constexpr int BM = 128, TB = 4, NPL = PREC ? 2 : 1;
+    constexpr int ALD = KS + 8;                            // slab row stride (bf16)
+    constexpr int BLD = TB * KS + 8;                       // weight stage row stride (bf16)
+    constexpr int CPR = KS / 8;                            // 16-byte chunks per slab row
+    constexpr int BCH = TB * KS / 8;                       // chunks per weight row per stage
+    constexpr int NB = (64 * BCH + 255) / 256;             // weight chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned short smw[];
+    const paa_gemm_desc& d = g.d;
+    const int srows = BM + taps - 1;
+    unsigned short* sA = smw;                              // [NPL][srows][ALD]
+    unsigned short* sB = smw + NPL * srows * ALD;          // [NPL][64][BLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int z = blockIdx.y, z1 = z / d.batch2, z2 = z - z1 * d.batch2;
+    const int64_t aoff = z1 * d.a_s1 + z2 * d.a_s2, boff = z1 * d.b_s1 + z2 * d.b_s2;
+    const unsigned short* Ap[2] = {reinterpret_cast<const unsigned short*>(d.A) + aoff,
+                                   PREC ? reinterpret_cast<const unsigned short*>(d.A_lo) + aoff : nullptr};
+    const unsigned short* Bp[2] = {reinterpret_cast<const unsigned short*>(d.B) + boff,
+                                   PREC ? reinterpret_cast<const unsigned short*>(d.B_lo) + boff : nullptr};
+    // slab: global row m0 - pad + sr, zero outside the clip
+    for (int i = tid; i < srows * CPR; i += 256) {
+        const int sr = i / CPR, ch = i - sr * CPR;
+        const int tr = m0 - d.a_pad + sr;
+        const bool ok = tr >= 0 && tr < d.a_rows_valid;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) x = *reinterpret_cast<const uint4*>(Ap[pl] + (int64_t)tr * d.lda + ch * 8);
+            *reinterpret_cast<uint4*>(sA + (pl * srows + sr) * ALD + ch * 8) = x;
+        }
+    }
+    // weight rows >= N stay zero for the whole kernel
+    for (int i = tid; i < NPL * 64 * BLD / 8; i += 256) reinterpret_cast<uint4*>(sB)[i] = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rb[NPL][NB];
+    auto bload = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * u;
+            const int n = i / BCH, ch = i - n * BCH;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                rb[pl][u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < 64 * BCH && n < d.N) rb[pl][u] = *reinterpret_cast<const uint4*>(Bp[pl] + (int64_t)n * d.ldb + st * (TB * KS) + ch * 8);
+            }
+        }
+    };
+    auto bstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * u;
+            const int n = i / BCH, ch = i - n * BCH;
+            if (i < 64 * BCH && n < d.N) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sB + (pl * 64 + n) * BLD + ch * 8) = rb[pl][u];
+            }
+        }
+    };
+    __syncthreads();                                       // zero fill before the first stage lands on top of it
+    bload(0);
+    bstore();
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+    const int nst = taps / TB;
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();                                   // stage st (and, first time, the slab) is in LDS
+        if (st + 1 < nst) bload(st + 1);
+#pragma unroll
+        for (int tp = 0; tp < TB; ++tp) {
+            const unsigned short* pa = sA + (wave * 32 + lr + st * TB + tp) * ALD + lh * 8;
+            const unsigned short* pb = sB + lr * BLD + tp * KS + lh * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS / 16; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
+                bf16x8 al;
+                if (PREC) al = *reinterpret_cast<const bf16x8*>(pa + srows * ALD + ks * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pb + j * 32 * BLD + ks * 16);
+                    if (PREC) {
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pb + (64 + j * 32) * BLD + ks * 16);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[0][j], 0, 0, 0);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[0][j], 0, 0, 0);
+                    }
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[0][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done with stage st
+        if (st + 1 < nst) bstore();
+    }
+    epilogue<2, 1>(d, acc, m0 + wave * 32 + 4 * lh, lr, z1, z2);
+}
+
 // resident workgroups of a kernel on this device (CUs x occupancy), cached per kernel
 template <typename K>
 static int resident_blocks(K kernel, int threads) {
@@ -782,6 +887,29 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
         g_prof.flops[g_prof.n] = 2.0 * d.M * d.N * (double)d.K * d.batch;
         g_prof.variant[g_prof.n] = (tall ? 32 : 0) + (d.operand_bf16 ? 16 : 0) + (narrow ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
+    }
+    // grouped positional convolution (and its dgrad): slab kernel
+    if (d.operand_bf16 && d.a_window && (d.a_kseg == 48 || d.a_kseg == 64) && d.N <= 64 && d.K % (4 * d.a_kseg) == 0 &&
+        d.ldb >= d.K && d.a_kseg_stride == d.lda) {
+        const int taps = d.K / d.a_kseg;
+        const int npl = d.precision ? 2 : 1;
+        const size_t lds = 2 * (size_t)npl * ((size_t)(128 + taps - 1) * (d.a_kseg + 8) + 64 * (size_t)(4 * d.a_kseg + 8));
+        if (lds <= 150 * 1024) {
+            dim3 wgrid(cdiv(d.M, 128), d.batch);
+#define PAA_WIN(P, KS_)                                                                                                      \
+            {                                                                                                                \
+                static bool attr = false;                                                                                    \
+                if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<P, KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
+                hipLaunchKernelGGL((k_gemm_win<P, KS_>), wgrid, dim3(256), lds, st, g, taps);                                \
+            }
+            if (prof) { g_prof.variant[g_prof.n] = 40 + (d.precision ? 4 : 0); }
+            if (d.a_kseg == 48) { if (d.precision) PAA_WIN(1, 48) else PAA_WIN(0, 48) }
+            else { if (d.precision) PAA_WIN(1, 64) else PAA_WIN(0, 64) }
+#undef PAA_WIN
+            if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }
+            PAA_LAUNCH_CHECK();
+            return PAA_OK;
+        }
     }
     if (d.operand_bf16) {
         const bool seg = d.a_kseg > 0 || (d.K & 63);          // segmented / windowed A or a K tail: general loader
