@@ -30,6 +30,8 @@ sys.path.insert(0, ROOT)
 VARIANTS = {v: (f"k_gemm_bf<{'256' if v & 32 else '128'},{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'}>" if v & 16 else
                 f"k_gemm<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'},A{'k' if v & 2 else 'm'},B{'k' if v & 1 else 'n'}>")
             for v in range(64)}
+VARIANTS.update({51: "k_gemm_bf<256,128,bf16>", 55: "k_gemm_bf<256,128,split>", 59: "k_gemm_bf<192,128,bf16>",
+                 40: "k_gemm_win<bf16>", 44: "k_gemm_win<split>"})
 
 
 def parse():

@@ -147,7 +147,8 @@ paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
 /* Measurement aid (bench.py roofline leg): HIP-event timing of every GEMM launch on its own stream.
  * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[64][3] =
  * {launches, total ms, total algorithmic FLOP (2*M*N*K*batch)} per kernel variant
- * (tileM256*32 + bf16_operands*16 + narrow*8 + split*4 + a_kcontig*2 + b_kcontig) and resets. */
+ * (tall*32 + bf16_operands*16 + (narrow | 192-row tall tile)*8 + split*4 + a_kcontig*2 + b_kcontig; 40 / 44 = slab kernel
+ * of the grouped positional convolution) and resets. */
 paa_status paa_prof_enable(int max_launches);
 paa_status paa_prof_read(double* out192);
 /* Fused attention (head_dim 64, bf16 planes as uint16): qkv (B*P, 3H) = Q|K|V, ctx/dctx (B*P, H), lse/delta (B*nh, Tp) */

@@ -10,7 +10,7 @@ from paa_amd import _lib
 L = _lib.lib()
 
 
-def run(name, M, N, K, lda=None, act=0, pre=False, outf=True, outb=False, prec=0, resid=False, iters=20, rowmask=0):
+def run(name, M, N, K, lda=None, act=0, pre=False, outf=True, outb=False, prec=0, resid=False, iters=20, rowmask=0, alias=False):
     lda = lda or K
     rows = M * lda // K + 8 if lda < K else M
     A = torch.randint(-2000, 2000, (max(M * lda + K, rows * K),), dtype=torch.int16, device="cuda")
@@ -24,7 +24,7 @@ def run(name, M, N, K, lda=None, act=0, pre=False, outf=True, outb=False, prec=0
     d = _lib.PaaGemmDesc()
     d.A, d.B = A.data_ptr(), B.data_ptr()
     d.A_lo, d.B_lo = Al.data_ptr(), Bl.data_ptr()
-    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, K, N
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, (0 if alias else lda), (0 if alias else K), N
     d.a_kcontig = d.b_kcontig = 1
     d.batch = d.batch2 = 1
     d.alpha = 1.0
@@ -62,6 +62,11 @@ def run(name, M, N, K, lda=None, act=0, pre=False, outf=True, outb=False, prec=0
 if __name__ == "__main__":
     import sys
     modes = [int(a) for a in sys.argv[1:]] or [1]
+    if modes == [3]:      # memory-latency probe: every A / B row aliases row 0 (lda = ldb = 0): operands always hit in cache
+        for (nm, M, N, K, it) in (("ffn2", 16000, 768, 3072, 20), ("ffn1", 16000, 3072, 768, 20), ("conv1", 512000, 512, 1536, 5)):
+            run(nm + " bf16 out", M, N, K, outf=False, outb=True, iters=it)
+            run(nm + " bf16 out, rows aliased", M, N, K, lda=8 * 0 + 0, outf=False, outb=True, iters=it, alias=True)
+        sys.exit(0)
     if modes == [2]:      # epilogue share: same product, different outputs
         for (nm, M, N, K, lda, it) in (("ffn1", 16000, 3072, 768, None, 20), ("qkv", 16000, 2304, 768, None, 20),
                                        ("outproj", 16000, 768, 768, None, 20), ("ffn2", 16000, 768, 3072, None, 20),
