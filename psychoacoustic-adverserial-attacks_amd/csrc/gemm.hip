@@ -694,277 +694,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     }
 }
 
-// ---- LDS-DMA operand ring (bf16 mode, regular shapes) --------------------------------------------------------------------
-// BM x BN x 64 tile, WM x WN waves of (BM / WM) x 64 each, TWO workgroups per CU.  Operand K tiles go global -> LDS with
-// global_load_lds_dwordx4 (no staging registers, no ds_write_b128 — whose VGPR -> LDS transfer costs ~13 cycles per
-// wave-instruction and competes with the fragment reads) into a 2-stage ring; the DMA of K tile k+1 (or of the next
-// output tile's first K tile) is issued right after the barrier that opens iteration k, one barrier per K tile; the
-// co-resident workgroup covers the rest of the load latency.  LDS rows are unpadded 128-byte K slices; bank conflicts are
-// removed by an XOR swizzle applied to the SOURCE chunk (position p = lane & 7 of ring row r receives global chunk
-// p ^ ((r >> 1) & 7)) and undone in the fragment reads.  B rows are permuted inside each 64-row group as store_bf<PERM>.
-typedef __attribute__((address_space(1))) const void* gas_ptr;
-typedef __attribute__((address_space(3))) void* las_ptr;
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void hard_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int BM, int BN, int WM>
-__global__ __launch_bounds__(WM * (BN / 64) * 64, 2) void k_gemm_dma(GemmArgs g) {
-    constexpr int WN = BN / 64, NW = WM * WN, NT = NW * 64, MI = BM / (32 * WM), NJ = 2, NS = 2;
-    constexpr int ROWS = BM + BN;                         // ring rows: A then B
-    constexpr int GPW = ROWS / 8 / NW;                    // DMA wave-instructions (8 rows each) per wave per K tile
-    constexpr int STAGE = ROWS * 128;                     // bytes
-    static_assert(BM % (NW * 8) == 0 && ROWS % (NW * 8) == 0, "tile rows must split evenly over the waves' DMA pieces");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int total = nwg * d.batch;
-    const int nk = d.K / 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    struct Tile { int m0, n0, z1, z2; };
-    auto decode = [&](int t) {
-        Tile c;
-        const int z = t / nwg, orig = t - z * nwg;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-        c.m0 = tm * BM; c.n0 = tn * BN;
-        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
-        return c;
-    };
-
-    // ---- load cursor: (tile lt, K tile lk) is the next piece to fetch ---------------------------------------------
-    int lt = blockIdx.x, lk = 0;
-    if (lt >= total) return;
-    const unsigned short* src[GPW];
-    auto set_src = [&](int t) {
-        const Tile c = decode(t);
-        const unsigned short* A = reinterpret_cast<const unsigned short*>(d.A) + c.z1 * d.a_s1 + c.z2 * d.a_s2;
-        const unsigned short* B = reinterpret_cast<const unsigned short*>(d.B) + c.z1 * d.b_s1 + c.z2 * d.b_s2;
-#pragma unroll
-        for (int i = 0; i < GPW; ++i) {
-            const int r = (i * NW + wave) * 8 + (lane >> 3);          // ring row: [0, BM) A, [BM, BM + BN) B
-            const int ch = (lane & 7) ^ ((r >> 1) & 7);               // global chunk that lands at position lane & 7
-            if (i * NW * 8 < BM) {                                    // this instruction's rows are A rows for every wave
-                src[i] = A + (int64_t)min(c.m0 + r, d.M - 1) * d.lda + ch * 8;
-            } else {
-                const int p = r - BM;
-                const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);
-                src[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
-            }
-        }
-    };
-    auto issue = [&](int stage) {
-        unsigned char* st = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < GPW; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lk * 64), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
-        if (++lk == nk) {
-            lk = 0;
-            lt += gridDim.x;
-            if (lt < total) set_src(lt);
-        }
-    };
-    set_src(lt);
-    issue(0);
-
-    // fragment addressing: row base + swizzled 16-byte chunk of the K step
-    const int sw = (lr >> 1) & 7;
-    int offk[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
-    const int arow = (wm * (32 * MI) + lr) * 128, brow = BM * 128 + (wn * 64 + lr) * 128;
-
-    int it = 0;                                            // K tiles consumed so far: ring stage = it & 1
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const Tile cur = decode(t);
-        f32x16 acc[MI][NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        for (int kt = 0; kt < nk; ++kt, ++it) {
-            wait_vmcnt<0>();                               // my pieces of this K tile have landed
-            hard_barrier();                                // everyone's have; everyone is done with the other stage
-            if (lt < total) issue((it + 1) & 1);
-            const unsigned char* sa = smem + (it & 1) * STAGE + arow;
-            const unsigned char* sb = smem + (it & 1) * STAGE + brow;
-            // fragments of K step ks+1 are requested before the MFMAs of step ks issue: a whole step (MI * NJ MFMAs,
-            // ~200 cycles) covers the LDS latency even when this wave is alone on its SIMD
-            bf16x8 af[2][MI], bf[2][NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sa + i * 4096 + offk[0]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[0][j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks + 1 < 4) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(sa + i * 4096 + offk[ks + 1]);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) bf[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[ks + 1]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-                if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
-            }
-        }
-        epilogue_vec<MI, true>(d, acc, cur.m0 + wm * (32 * MI), cur.n0 + wn * 64, cur.z1, cur.z2, lane);
-    }
-}
-
-// ---- 256 x 256 x 64 tile, one 4-wave workgroup per CU, 128 x 128 per wave (bf16 mode, regular shapes) -------------------
-// The CU's vector-memory path feeds LDS at ~70 GB/s from L2 and ~35-45 GB/s from the Infinity Cache (MI355X_MICROARCH,
-// "Indexed rows: gather into LDS"), and a pair of 256 x 128 tiles needs 96 KB per K step of 64 against 64 KB for one
-// 256 x 256 tile: the square tile is what lets the matrix pipes — not the operand stream — set the pace.  Its 256
-// accumulator registers per lane leave room for one wave per SIMD only, so everything is software-pipelined inside the
-// wave: the operand stream is a flat sequence of (output tile, K tile) pieces; a piece is requested into registers one
-// iteration before it is written to the idle half of a double-buffered LDS tile (between the MFMAs of the current
-// piece, one barrier per piece), and the fragments of K step ks+1 are read while the 16 MFMAs of step ks issue.
-__global__ __launch_bounds__(256, 1) void k_gemm_xl(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NT = 256, MI = 4;
-    constexpr int BUF = (BM + BN) * H_LD;                  // bf16 elements per LDS buffer (73,728 B)
-    constexpr int NR = BM * 8 / NT;                        // 16-byte chunks per thread per operand per piece = 8
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int total = nwg * d.batch;
-    const int nk = d.K / H_BK;
-    struct Tile { int m0, n0, z1, z2; };
-    auto decode = [&](int t) {
-        Tile c;
-        const int z = t / nwg, orig = t - z * nwg;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-        c.m0 = tm * BM; c.n0 = tn * BN;
-        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
-        return c;
-    };
-    int t = blockIdx.x;
-    if (t >= total) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    // ---- load cursor ------------------------------------------------------------------------------------------------
-    int lt = t, lk = 0;
-    Tile lc = decode(lt);
-    const unsigned kc = (unsigned)((tid & 7) << 3);
-    const unsigned va = 2u * ((unsigned)(tid >> 3) * (unsigned)d.lda + kc), vb = 2u * ((unsigned)(tid >> 3) * (unsigned)d.ldb + kc);
-    const unsigned sa = 2u * (NT / 8) * (unsigned)d.lda, sb = 2u * (NT / 8) * (unsigned)d.ldb;
-    auto gload = [&](uint4 (&ra)[NR], uint4 (&rb)[NR]) {
-        if (lt >= total) return;
-        const int64_t a0 = lc.z1 * d.a_s1 + lc.z2 * d.a_s2 + (int64_t)lc.m0 * d.lda, b0 = lc.z1 * d.b_s1 + lc.z2 * d.b_s2 + (int64_t)lc.n0 * d.ldb;
-        const int64_t ae = (int64_t)(d.M - 1 - lc.m0) * d.lda + d.K, be = (int64_t)(d.N - 1 - lc.n0) * d.ldb + d.K;
-        load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A) + a0, ae), va, 2u * H_BK * lk, sa, ra);
-        load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * H_BK * lk, sb, rb);
-        if (++lk == nk) {
-            lk = 0;
-            lt += gridDim.x;
-            if (lt < total) lc = decode(lt);
-        }
-    };
-    // registers -> LDS, one quarter (2 + 2 chunks) at a time so the stores can sit between MFMA groups
-    auto lstore_q = [&](unsigned short* buf, const uint4 (&ra)[NR], const uint4 (&rb)[NR], int qtr) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = 2 * qtr + u;
-            const int r = (tid >> 3) + (NT / 8) * i;
-            *reinterpret_cast<uint4*>(buf + r * H_LD + ((tid & 7) << 3)) = ra[i];
-            const int rp = (r & ~63) | ((((r >> 2) & 1) << 5) + (((r & 63) >> 3) << 2) + (r & 3));      // store_bf<PERM>
-            *reinterpret_cast<uint4*>(buf + (BM + rp) * H_LD + ((tid & 7) << 3)) = rb[i];
-        }
-    };
-
-    f32x16 acc[2][MI][2];                                  // [column half jh][i][j]: columns wn*128 + jh*64 + j*32
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[jh][i][j][e] = 0.f;
-    };
-
-    // Pipeline: while piece n is multiplied out of LDS buffer n & 1, piece n+1 (in the registers since the last
-    // iteration) is written to the other buffer between the MFMA groups, and piece n+2 is requested right after.
-    const int my_tiles = (total - t + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int npieces = my_tiles * nk;
-    uint4 ra[NR], rb[NR];
-    gload(ra, rb);                                         // piece 0
-#pragma unroll
-    for (int qtr = 0; qtr < 4; ++qtr) lstore_q(smem, ra, rb, qtr);
-    gload(ra, rb);                                         // piece 1 (if any)
-    Tile cur = decode(t);
-    int k = 0;
-    zero_acc();
-    for (int n = 0; n < npieces; ++n) {
-        // registers hold piece n+1; buffer (n+1)&1 was last read for piece n-1
-        unsigned short* bufc = smem + (n & 1) * BUF;
-        unsigned short* bufn = smem + ((n + 1) & 1) * BUF;
-        __syncthreads();                                   // piece n is complete in bufc; everyone has left bufn
-        const unsigned short* pa = bufc + (wm * 128 + lr) * H_LD + lh * 8;
-        const unsigned short* pb = bufc + BM * H_LD + (wn * 128 + lr) * H_LD + lh * 8;
-        const bool wr = n + 1 < npieces;
-        bf16x8 af[2][MI], bq[2][4];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * H_LD);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bq[0][c] = *reinterpret_cast<const bf16x8*>(pb + c * 32 * H_LD);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * H_LD + (ks + 1) * 16);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) bq[(ks + 1) & 1][c] = *reinterpret_cast<const bf16x8*>(pb + c * 32 * H_LD + (ks + 1) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[c >> 1][i][c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bq[ks & 1][c], acc[c >> 1][i][c & 1], 0, 0, 0);
-            if (wr) lstore_q(bufn, ra, rb, ks);            // piece n+1 -> the idle buffer, a quarter per K step
-            if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-        }
-        gload(ra, rb);                                     // piece n+2 into the freed registers (no-op past the end)
-        if (++k == nk) {
-            epilogue_vec<MI, true>(d, acc[0], cur.m0 + wm * 128, cur.n0 + wn * 128, cur.z1, cur.z2, lane);
-            epilogue_vec<MI, true>(d, acc[1], cur.m0 + wm * 128, cur.n0 + wn * 128 + 64, cur.z1, cur.z2, lane);
-            k = 0; t += gridDim.x;
-            if (t < total) cur = decode(t);
-            zero_acc();
-        }
-    }
-}
-
 // ---- grouped positional convolution: windowed A, slab in LDS ------------------------------------------------------------
 // C[z][m][n] = sum_{tap} sum_{ci < KS} A_z[m + tap - pad][ci] * B_z2[n][tap * KS + ci], rows outside [0, a_rows_valid) zero
 // (a_window products with a_kseg = KS in {48, 64}, N <= 64: wav2vec2's 128-tap grouped conv and its dgrad).  Through
@@ -1190,20 +919,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         }
         else if (seg) { if (d.precision) launch_bf<128, 128, 1, 2, false, true>(g, st); else launch_bf<128, 128, 0, 2, false, true>(g, st); }
         else if (tall) {
-            static const int variant = getenv("PAA_GEMM_V") ? atoi(getenv("PAA_GEMM_V")) : 0;      // measurement knob
             if (d.precision) launch_bf<256, 128, 1, 4, true, false>(g, st);
-            else if (variant == 4 && d.N >= 256) {
-                static const int resident = resident_blocks(k_gemm_xl, 256);
-                g.tiles_m = cdiv(d.M, 256); g.tiles_n = cdiv(d.N, 256);
-                const int total = g.tiles_m * g.tiles_n * d.batch;
-                hipLaunchKernelGGL(k_gemm_xl, dim3(resident > 0 ? std::min(total, resident) : total), dim3(256), 0, st, g);
-            }
-            else if (variant == 2 || (variant == 3 && bm192)) {
-                static const int resident = resident_blocks(k_gemm_dma<192, 128, 2>, 256);
-                g.tiles_m = cdiv(d.M, 192);
-                const int total = g.tiles_m * g.tiles_n * d.batch;
-                hipLaunchKernelGGL((k_gemm_dma<192, 128, 2>), dim3(resident > 0 ? std::min(total, resident) : total), dim3(256), 0, st, g);
-            }
             else if (bm192) launch_bf<192, 128, 0, 2, true, false>(g, st);
             else launch_bf<256, 128, 0, 2, true, false>(g, st);
         }
