@@ -203,10 +203,11 @@ def main():
             # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
             # this same command (profiles/r1_hbm_traffic_pmc.json, FETCH_SIZE doubled per the gfx950 correction); null if absent
             traffic = None
+            pmc_name = {51: "k_gemm_bf<256, 128, 0, 2,", 59: "k_gemm_bf<192, 128, 0, 2,", 55: "k_gemm_bf<256, 128, 1, 4,"}.get(v)
             try:
                 with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic_pmc.json")) as f:
                     for k in json.load(f)["kernels"]:
-                        if VARIANTS[v].startswith("k_gemm_bf<256") and "k_gemm_bf<256, 128, 0, 4>" in k["kernel"] and ar.dtype == "bf16":
+                        if pmc_name and pmc_name in k["kernel"] and ar.dtype == "bf16" and B == 32 and ar.arch == "base":
                             traffic = k["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
