@@ -694,134 +694,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     }
 }
 
-// ---- 256 x 256 x 64 tile, one 8-wave workgroup per CU (bf16 mode, regular shapes with N >= 256) -------------------------
-// The CU's vector-memory path feeds LDS at ~70 GB/s from L2 and 35-45 GB/s from the Infinity Cache (MI355X_MICROARCH,
-// "Indexed rows: gather into LDS"); two co-resident 256 x 128 tiles need 96 KB per K step of 64, one 256 x 256 tile 64 KB
-// for the same FLOPs.  8 waves as 2 (M) x 4 (N), 128 x 64 per wave.  The operand stream is a flat sequence of
-// (output tile, K tile) pieces: a piece is requested into registers (buffer loads, 4 + 4 chunks per thread) one
-// iteration before it is written — a quarter per K step, between the MFMA groups — to the idle half of a
-// double-buffered LDS tile, so there is one barrier per piece, the stores hide under the MFMAs, and output-tile
-// boundaries do not drain the pipeline (the next tile's first piece is already in LDS during the epilogue).
-__global__ __launch_bounds__(512, 2) void k_gemm_sq(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NT = 512, MI = 4, NJ = 2;
-    constexpr int BUF = (BM + BN) * H_LD;                  // bf16 elements per LDS buffer (73,728 B)
-    constexpr int NR = BM * 8 / NT;                        // 16-byte chunks per thread per operand per piece = 4
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int total = nwg * d.batch;
-    const int nk = d.K / H_BK;
-    struct Tile { int m0, n0, z1, z2; };
-    auto decode = [&](int t) {
-        Tile c;
-        const int z = t / nwg, orig = t - z * nwg;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-        c.m0 = tm * BM; c.n0 = tn * BN;
-        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
-        return c;
-    };
-    int t = blockIdx.x;
-    if (t >= total) return;
-
-    // ---- load cursor ------------------------------------------------------------------------------------------------
-    int lt = t, lk = 0;
-    Tile lc = decode(lt);
-    uint4 ra[NR], rb[NR];
-    auto gload = [&](int tid) {
-        if (lt >= total) return;
-        const unsigned kc = (unsigned)((tid & 7) << 3);
-        const unsigned va = 2u * ((unsigned)(tid >> 3) * (unsigned)d.lda + kc), vb = 2u * ((unsigned)(tid >> 3) * (unsigned)d.ldb + kc);
-        const unsigned sa = 2u * (NT / 8) * (unsigned)d.lda, sb = 2u * (NT / 8) * (unsigned)d.ldb;
-        const int64_t a0 = lc.z1 * d.a_s1 + lc.z2 * d.a_s2 + (int64_t)lc.m0 * d.lda, b0 = lc.z1 * d.b_s1 + lc.z2 * d.b_s2 + (int64_t)lc.n0 * d.ldb;
-        const int64_t ae = (int64_t)(d.M - 1 - lc.m0) * d.lda + d.K, be = (int64_t)(d.N - 1 - lc.n0) * d.ldb + d.K;
-        load_buf<BM, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.A) + a0, ae), va, 2u * H_BK * lk, sa, ra);
-        load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * H_BK * lk, sb, rb);
-        if (++lk == nk) {
-            lk = 0;
-            lt += gridDim.x;
-            if (lt < total) lc = decode(lt);
-        }
-    };
-    // registers -> LDS: chunk i of A and of B (B rows permuted inside 64-row groups as store_bf<PERM>)
-    auto lstore_q = [&](unsigned short* buf, int i, int tid) {
-        const int r = (tid >> 3) + (NT / 8) * i;
-        *reinterpret_cast<uint4*>(buf + r * H_LD + ((tid & 7) << 3)) = ra[i];
-        const int rp = (r & ~63) | ((((r >> 2) & 1) << 5) + (((r & 63) >> 3) << 2) + (r & 3));
-        *reinterpret_cast<uint4*>(buf + (BM + rp) * H_LD + ((tid & 7) << 3)) = rb[i];
-    };
-
-    const int my_tiles = (total - t + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int npieces = my_tiles * nk;
-    gload(threadIdx.x);                                    // piece 0
-#pragma unroll
-    for (int i = 0; i < NR; ++i) lstore_q(smem, i, threadIdx.x);
-    gload(threadIdx.x);                                    // piece 1 (if any)
-    Tile cur = decode(t);
-    int k = 0;
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    for (int n = 0; n < npieces; ++n) {
-        // registers hold piece n+1; buffer (n+1)&1 was last read for piece n-1
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));                      // addresses below are recomputed per piece, not kept across the epilogue
-        const int lane = tid & 63, wave = tid >> 6;
-        const int wm = wave >> 2, wn = wave & 3, lr = lane & 31, lh = lane >> 5;
-        unsigned short* bufc = smem + (n & 1) * BUF;
-        unsigned short* bufn = smem + ((n + 1) & 1) * BUF;
-        __syncthreads();                                   // piece n is complete in bufc; everyone has left bufn
-        const unsigned short* pa = bufc + (wm * 128 + lr) * H_LD + lh * 8;
-        const unsigned short* pb = bufc + BM * H_LD + (wn * 64 + lr) * H_LD + lh * 8;
-        const bool wr = n + 1 < npieces;
-        bf16x8 af[2][MI], bq[2][NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * H_LD);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bq[0][j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD);
-        __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * H_LD + (ks + 1) * 16);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) bq[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD + (ks + 1) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bq[ks & 1][j], acc[i][j], 0, 0, 0);
-            if (wr) lstore_q(bufn, ks, tid);               // piece n+1 -> the idle buffer, a quarter per K step
-            if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        gload(tid);                                        // piece n+2 into the freed registers (no-op past the end)
-        if (++k == nk) {
-            epilogue_vec<MI, true>(d, acc, cur.m0 + wm * 128, cur.n0 + wn * 64, cur.z1, cur.z2, lane);
-            k = 0; t += gridDim.x;
-            if (t < total) cur = decode(t);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        }
-    }
-}
-
 // ---- grouped positional convolution: windowed A, slab in LDS ------------------------------------------------------------
 // C[z][m][n] = sum_{tap} sum_{ci < KS} A_z[m + tap - pad][ci] * B_z2[n][tap * KS + ci], rows outside [0, a_rows_valid) zero
 // (a_window products with a_kseg = KS in {48, 64}, N <= 64: wav2vec2's 128-tap grouped conv and its dgrad).  Through
@@ -1047,14 +919,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         }
         else if (seg) { if (d.precision) launch_bf<128, 128, 1, 2, false, true>(g, st); else launch_bf<128, 128, 0, 2, false, true>(g, st); }
         else if (tall) {
-            static const int variant = getenv("PAA_GEMM_V") ? atoi(getenv("PAA_GEMM_V")) : 0;      // measurement knob
             if (d.precision) launch_bf<256, 128, 1, 4, true, false>(g, st);
-            else if (variant == 5 && d.N >= 256) {
-                static const int resident = resident_blocks(k_gemm_sq, 512);
-                g.tiles_m = cdiv(d.M, 256); g.tiles_n = cdiv(d.N, 256);
-                const int total = g.tiles_m * g.tiles_n * d.batch;
-                hipLaunchKernelGGL(k_gemm_sq, dim3(resident > 0 ? std::min(total, resident) : total), dim3(512), 0, st, g);
-            }
             else if (bm192) launch_bf<192, 128, 0, 2, true, false>(g, st);
             else launch_bf<256, 128, 0, 2, true, false>(g, st);
         }
