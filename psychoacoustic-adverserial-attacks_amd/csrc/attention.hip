@@ -98,6 +98,23 @@ __device__ __forceinline__ void store_own(unsigned short* __restrict__ dst, int6
         }
 }
 
+// Workgroup -> (head bh, 128-position block ob).  The nb blocks of one head re-read the same K / V (or Q / dO) rows;
+// consecutive workgroup ids go round-robin over the 8 XCDs, so ids are decoded such that all blocks of a head carry the
+// same id % 8 (one XCD's L2 serves the re-reads) and are dispatched close together: 8 heads x nb blocks per group.
+__device__ __forceinline__ void attn_block(int nb, int nheads, int& bh, int& ob) {
+    const int id = blockIdx.x;
+    const int full = (nheads / 8) * 8 * nb;               // ids covered by complete groups of 8 heads
+    if (id < full) {
+        const int grp = id / (8 * nb), r = id - grp * 8 * nb;
+        ob = r >> 3;
+        bh = grp * 8 + (r & 7);
+    } else {                                              // tail (fewer than 8 heads left): plain order
+        const int r = id - full;
+        bh = (nheads / 8) * 8 + r / nb;
+        ob = r - (r / nb) * nb;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // 64 keys per iteration (two 32-key score tiles), K / V tiles double-buffered in LDS and prefetched through registers:
 // one barrier per 64 keys, 16 MFMAs per wave between barriers.
@@ -105,9 +122,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnArgs a) {
     constexpr int KT = 64;
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][KT * AT_RM];
     __shared__ __attribute__((aligned(16))) unsigned short sV[2][KT * AT_RM];
-    const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
+    int bh, oblk;
+    attn_block((a.T + 127) / 128, a.nbh, bh, oblk);
+    const int b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
-    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    const int q = oblk * 128 + wave * 32 + lr;
     const int qc = q < a.T ? q : a.T - 1;
     const int64_t ld = 3 * (int64_t)a.H;
     const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
@@ -200,9 +219,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnArgs a) {
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sKb[2][32 * AT_RM];
     __shared__ __attribute__((aligned(16))) unsigned short sVb[2][32 * AT_RM];
-    const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
+    int bh, oblk;
+    attn_block((a.T + 127) / 128, a.nbh, bh, oblk);
+    const int b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
-    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    const int q = oblk * 128 + wave * 32 + lr;
     const int qc = q < a.T ? q : a.T - 1;
     const int64_t ld = 3 * (int64_t)a.H;
     const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
@@ -275,9 +296,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sQb[2][32 * AT_RM];
     __shared__ __attribute__((aligned(16))) unsigned short sdOb[2][32 * AT_RM];
     __shared__ float sLseb[2][32], sDelb[2][32];
-    const int bh = blockIdx.y, b = bh / a.nh, h = bh - b * a.nh;
+    int bh, oblk;
+    attn_block((a.T + 127) / 128, a.nbh, bh, oblk);
+    const int b = bh / a.nh, h = bh - b * a.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
-    const int key = blockIdx.x * 128 + wave * 32 + lr;
+    const int key = oblk * 128 + wave * 32 + lr;
     const int kc = key < a.T ? key : a.T - 1;
     const int64_t ld = 3 * (int64_t)a.H;
     const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
@@ -365,16 +388,18 @@ static paa_status attn_check(const AttnArgs& a, int B, int head_dim) {
 
 paa_status attn_fwd(const AttnArgs& a, int B, int head_dim, hipStream_t st) {
     PAA_TRY(attn_check(a, B, head_dim));
-    hipLaunchKernelGGL(k_attn_fwd, dim3(cdiv(a.T, 128), B * a.nh), dim3(256), 0, st, a);
+    AttnArgs f = a; f.nbh = B * a.nh;
+    hipLaunchKernelGGL(k_attn_fwd, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
 
 paa_status attn_bwd(const AttnArgs& a, int B, int head_dim, hipStream_t st) {
     PAA_TRY(attn_check(a, B, head_dim));
-    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(cdiv(a.T, 128), B * a.nh), dim3(256), 0, st, a);
+    AttnArgs f = a; f.nbh = B * a.nh;
+    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
     PAA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(cdiv(a.T, 128), B * a.nh), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }

@@ -67,6 +67,7 @@ struct AttnArgs {
     float* delta;                   // (B*nh, Tp) rowsum(dO * O)
     unsigned short* dqkv;           // (M, 3H): dQ | dK | dV
     int T, P, Tp, H, nh;
+    int nbh;                        // B * nh (set by the launcher)
     float scale;                    // head_dim^-0.5
 };
 paa_status attn_fwd(const AttnArgs& a, int B, int head_dim, hipStream_t st);
