@@ -13,7 +13,6 @@
 // (e & 3) + 8 (e >> 2) + 4 lh of a 32 x 32 block) and share the epilogue contract of gemm.h.  The K-contiguous loaders
 // take an arbitrary (even overlapping) row stride — which is how the strided 1-D convolutions become plain GEMMs on a
 // channel-last layout.  What was tried and dropped on the main loop is recorded in DESIGN.md section 9.
-#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 
@@ -697,154 +696,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     }
 }
 
-// ---- LDS-DMA operand ring (bf16 mode, regular shapes) --------------------------------------------------------------------
-// BM x BN x 64 tile, WM x WN waves of (BM / WM) x 64 each, TWO workgroups per CU.  Operand K tiles go global -> LDS with
-// global_load_lds_dwordx4 (no staging registers, no ds_write_b128 — whose VGPR -> LDS transfer costs ~13 cycles per
-// wave-instruction and competes with the fragment reads) into a 2-stage ring; the DMA of K tile k+1 (or of the next
-// output tile's first K tile) is issued right after the barrier that opens iteration k, one barrier per K tile; the
-// co-resident workgroup covers the rest of the load latency.  LDS rows are unpadded 128-byte K slices; bank conflicts are
-// removed by an XOR swizzle applied to the SOURCE chunk (position p = lane & 7 of ring row r receives global chunk
-// p ^ ((r >> 1) & 7)) and undone in the fragment reads.  B rows are permuted inside each 64-row group as store_bf<PERM>.
-typedef __attribute__((address_space(1))) const void* gas_ptr;
-typedef __attribute__((address_space(3))) void* las_ptr;
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void hard_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int BM, int BN, int WM, int NS>
-__global__ __launch_bounds__(WM * (BN / 64) * 64, 1) void k_gemm_dma(GemmArgs g) {
-    constexpr int WN = BN / 64, NW = WM * WN, NT = NW * 64, MI = BM / (32 * WM), NJ = 2;
-    constexpr int ROWS = BM + BN;                         // ring rows: A then B
-    constexpr int GPW = ROWS / 8 / NW;                    // DMA wave-instructions (8 rows each) per wave per K tile
-    constexpr int STAGE = ROWS * 128;                     // bytes
-    static_assert(BM % (NW * 8) == 0 && ROWS % (NW * 8) == 0, "tile rows must split evenly over the waves' DMA pieces");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
-
-    const paa_gemm_desc& d = g.d;
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int total = nwg * d.batch;
-    const int nk = d.K / 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int lr = lane & 31, lh = lane >> 5;
-
-    struct Tile { int m0, n0, z1, z2; };
-    auto decode = [&](int t) {
-        Tile c;
-        const int z = t / nwg, orig = t - z * nwg;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
-        c.m0 = tm * BM; c.n0 = tn * BN;
-        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
-        return c;
-    };
-
-    // ---- load cursor: (tile lt, K tile lk) is the next piece to fetch ---------------------------------------------
-    int lt = blockIdx.x, lk = 0;
-    if (lt >= total) return;
-    const unsigned short* src[GPW];
-    auto set_src = [&](int t) {
-        const Tile c = decode(t);
-        const unsigned short* A = reinterpret_cast<const unsigned short*>(d.A) + c.z1 * d.a_s1 + c.z2 * d.a_s2;
-        const unsigned short* B = reinterpret_cast<const unsigned short*>(d.B) + c.z1 * d.b_s1 + c.z2 * d.b_s2;
-#pragma unroll
-        for (int i = 0; i < GPW; ++i) {
-            const int r = (i * NW + wave) * 8 + (lane >> 3);          // ring row: [0, BM) A, [BM, BM + BN) B
-            const int ch = (lane & 7) ^ ((r >> 1) & 7);               // global chunk that lands at position lane & 7
-            if (i * NW * 8 < BM) {                                    // this instruction's rows are A rows for every wave
-                src[i] = A + (int64_t)min(c.m0 + r, d.M - 1) * d.lda + ch * 8;
-            } else {
-                const int p = r - BM;
-                const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);
-                src[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
-            }
-        }
-    };
-    auto issue = [&](int stage) {
-        unsigned char* st = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < GPW; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lk * 64), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
-        if (++lk == nk) {
-            lk = 0;
-            lt += gridDim.x;
-            if (lt < total) set_src(lt);
-        }
-    };
-    set_src(lt);
-    issue(0);                                              // pieces 0 .. NS-2 are in flight before the first MFMA
-    int issued = 1;
-    const int my_tiles = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int npieces = my_tiles * nk;
-    for (; issued < NS - 1 && issued < npieces; ++issued) issue(issued % NS);
-
-    // fragment addressing: row base + swizzled 16-byte chunk of the K step
-    const int sw = (lr >> 1) & 7;
-    int offk[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
-    const int arow = (wm * (32 * MI) + lr) * 128, brow = BM * 128 + (wn * 64 + lr) * 128;
-
-    int it = 0;                                            // K tiles consumed so far: ring stage = it % NS
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const Tile cur = decode(t);
-        f32x16 acc[MI][NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        for (int kt = 0; kt < nk; ++kt, ++it) {
-            // my pieces of K tile `it` have landed; up to NS-2 younger pieces stay in flight (vmcnt is in issue order)
-            if (issued - it - 1 >= NS - 2 && NS > 2) wait_vmcnt<(NS > 2 ? (NS - 2) * GPW : 0)>(); else wait_vmcnt<0>();
-            hard_barrier();                                // everyone's have; everyone is done with the stage refilled next
-            if (issued < npieces) { issue(issued % NS); ++issued; }
-            const unsigned char* sa = smem + (it % NS) * STAGE + arow;
-            const unsigned char* sb = smem + (it % NS) * STAGE + brow;
-            bf16x8 bh[NJ], bhn[NJ], ah, ahn;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { bh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[0]); bhn[j] = bh[j]; }
-            ah = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
-            ahn = ah;
-            __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
-                    if (nks < 4) {
-                        ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 4096 + offk[nks]);
-                        if (ni == 0) {
-#pragma unroll
-                            for (int j = 0; j < NJ; ++j) bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 4096 + offk[nks]);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                    if (nks < 4) {
-                        if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, NJ + 1, 0);
-                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
-                    ah = ahn;
-                    if (ni == 0) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) bh[j] = bhn[j];
-                    }
-                }
-        }
-        epilogue_vec<MI, true>(d, acc, cur.m0 + wm * (32 * MI), cur.n0 + wn * 64, cur.z1, cur.z2, lane);
-    }
-}
-
 // ---- grouped positional convolution: windowed A, slab in LDS ------------------------------------------------------------
 // C[z][m][n] = sum_{tap} sum_{ci < KS} A_z[m + tap - pad][ci] * B_z2[n][tap * KS + ci], rows outside [0, a_rows_valid) zero
 // (a_window products with a_kseg = KS in {48, 64}, N <= 64: wav2vec2's 128-tap grouped conv and its dgrad).  Through
@@ -1070,14 +921,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         }
         else if (seg) { if (d.precision) launch_bf<128, 128, 1, 2, false, true>(g, st); else launch_bf<128, 128, 0, 2, false, true>(g, st); }
         else if (tall) {
-            static const int variant = getenv("PAA_GEMM_V") ? atoi(getenv("PAA_GEMM_V")) : 0;      // measurement knob
             if (d.precision) launch_bf<256, 128, 1, 4, true, false>(g, st);
-            else if (variant == 6) {
-                static const int resident = resident_blocks(k_gemm_dma<256, 128, 2, 3>, 256);
-                g.tiles_m = cdiv(d.M, 256);
-                const int total = g.tiles_m * g.tiles_n * d.batch;
-                hipLaunchKernelGGL((k_gemm_dma<256, 128, 2, 3>), dim3(resident > 0 ? std::min(total, resident) : total), dim3(256), 0, st, g);
-            }
             else if (bm192) launch_bf<192, 128, 0, 2, true, false>(g, st);
             else launch_bf<256, 128, 0, 2, true, false>(g, st);
         }
