@@ -163,7 +163,7 @@ __device__ __forceinline__ float in_sample(const Conv0Args& a, int b, int i) {
     return v;
 }
 
-constexpr int C0_TCH = 64;   // frames per workgroup in the channel-per-thread kernels
+constexpr int C0_TCH = 128;  // frames per workgroup in the channel-per-thread kernels
 
 // Channel-per-thread mapping (thread owns channels tid, tid+256, ...; loops over a chunk of frames).
 // MODE 1: apply GroupNorm + GELU                                    -> pre[b][t][c], act[b][t][c]
@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void k_conv0_gn_stats(Conv0Args a, const doubl
     }
 }
 
-// Reduce the per-chunk partials in f64.  MODE 0: (sum, sumsq) -> (mean, rstd);  MODE 2: -> (s1/n, s2/n)
+// Reduce the per-chunk partials of the GroupNorm backward sums in f64: -> (s1 / n, s2 / n) per (clip, channel)
 __global__ __launch_bounds__(256) void k_conv0_gn_finalize(const float* __restrict__ part, float* __restrict__ out,
-                                                          int B, int C, int nchunk, int n, float eps, int mode) {
+                                                          int B, int C, int nchunk, int n) {
     // 64 (b, c) pairs per block, 4 chunk-slices each (fixed summation order => reproducible)
     __shared__ double sh1[4][64], sh2[4][64];
     const int pair = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -371,16 +371,8 @@ __global__ __launch_bounds__(256) void k_conv0_gn_finalize(const float* __restri
     if (slice != 0 || i >= B * C) return;
     s1 = (sh1[0][pair] + sh1[1][pair]) + (sh1[2][pair] + sh1[3][pair]);
     s2 = (sh2[0][pair] + sh2[1][pair]) + (sh2[2][pair] + sh2[3][pair]);
-    if (mode == 0) {
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        out[2 * (size_t)i] = (float)mean;
-        out[2 * (size_t)i + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    } else {
-        out[2 * (size_t)i] = (float)(s1 / n);
-        out[2 * (size_t)i + 1] = (float)(s2 / n);
-    }
+    out[2 * (size_t)i] = (float)(s1 / n);
+    out[2 * (size_t)i + 1] = (float)(s2 / n);
 }
 
 // Wave-per-frame mapping: lane owns channels lane, lane+64, ... (C <= 512).
@@ -638,7 +630,7 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
     hipLaunchKernelGGL(k_conv0_gn<2>, dim3(nchunk, a.B), dim3(256), lds, st, b);     // s1 = mean_t dy, s2 = mean_t dy*xhat
     PAA_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 64)), dim3(256), 0, st, (const float*)part,
-                       (float*)a.gn_bsums, a.B, a.C, nchunk, a.T, a.eps, 2);
+                       (float*)a.gn_bsums, a.B, a.C, nchunk, a.T);
     PAA_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a);
     PAA_LAUNCH_CHECK();
