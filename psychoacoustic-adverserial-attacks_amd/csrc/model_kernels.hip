@@ -560,32 +560,45 @@ __global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a) {
         }
 }
 
-// grad[l] = sum_b mask_b[l] * sum_{(t, j): t*stride + j = l} G[b][t][j], G from the GEMM result G1 (see above)
-__global__ void k_input_grad_gn(Conv0Args a, float* __restrict__ grad) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= a.L) return;
-    float total = 0.f;
-    int t_hi = l / a.stride;
-    int t_lo = (l - a.k + 1 + a.stride - 1);
+// grad[l] = sum_b mask_b[l] * sum_{(t, j): t*stride + j = l} G[b][t][j], G from the GEMM result G1 (see above).
+// A workgroup owns 256 consecutive samples and walks the clips in order (fixed summation order); per clip the input
+// window it needs, Mx_b and kc_b are staged in LDS once instead of being recomputed / re-read per (frame, tap).
+__global__ __launch_bounds__(256) void k_input_grad_gn(Conv0Args a, float* __restrict__ grad) {
+    __shared__ float xs[256 + 2 * 10 + 4];
+    __shared__ float smx[10 * 10], skc[16];
+    const int l0 = blockIdx.x * 256, l = l0 + threadIdx.x;
+    const int lc = l < a.L ? l : a.L - 1;
+    int t_hi = lc / a.stride;
+    int t_lo = (lc - a.k + 1 + a.stride - 1);
     t_lo = t_lo <= 0 ? 0 : t_lo / a.stride;
     if (t_hi > a.T - 1) t_hi = a.T - 1;
-#pragma unroll 4
-    for (int b = 0; b < a.B; ++b) {          // unrolled: the G1 reads of 4 clips are in flight together
+    const int w0 = l0 - a.k;                                  // first sample of the staged window
+    float total = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        __syncthreads();                                      // everyone is done with the previous clip's tiles
+        for (int i = threadIdx.x; i < 256 + 2 * a.k; i += 256) {
+            const int sidx = w0 + i;
+            xs[i] = (sidx >= 0 && sidx < a.L) ? in_sample(a, b, sidx) : 0.f;
+        }
+        if (threadIdx.x < a.k * a.k) smx[threadIdx.x] = a.Mx[(size_t)b * a.k * a.k + threadIdx.x];
+        if (threadIdx.x < 16) skc[threadIdx.x] = a.kc[(size_t)b * 16 + threadIdx.x];
+        __syncthreads();
         float gsum = 0.f;
         for (int t = t_lo; t <= t_hi; ++t) {
-            const int j = l - t * a.stride;
-            float g = a.G1[((size_t)b * a.P + t) * 16 + j] + a.kc[(size_t)b * 16 + j];
-            const float* mx = a.Mx + ((size_t)b * a.k + j) * a.k;
-            for (int q = 0; q < a.k; ++q) g -= mx[q] * in_sample(a, b, t * a.stride + q);
+            const int j = lc - t * a.stride;
+            float g = a.G1[((size_t)b * a.P + t) * 16 + j] + skc[j];
+            const float* mx = smx + j * a.k;
+            const float* xw = xs + (t * a.stride - w0);
+            for (int q = 0; q < a.k; ++q) g -= mx[q] * xw[q];
             gsum += g;
         }
         if (a.p && a.clamp) {
-            const float u = a.clean[(size_t)b * a.L + l] + a.p[l];
+            const float u = a.clean[(size_t)b * a.L + lc] + a.p[lc];
             if (!(u >= -1.f && u <= 1.f)) gsum = 0.f;           // clamp backward: pass-through inside [-1, 1]
         }
         total += gsum;
     }
-    grad[l] = total;
+    if (l < a.L) grad[l] = total;
 }
 
 paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st) {
