@@ -148,7 +148,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     paa_model* m = new paa_model();
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
     m->fused = (m->prec == 0) && (a.hidden / a.heads == 64);
-    m->pre16 = m->prec == 0 && !(getenv("PAA_PRE16") && atoi(getenv("PAA_PRE16")) == 0);      // env: A/B measurement knob
+    m->pre16 = m->prec == 0;
     for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
 
     // ---- shapes: conv output lengths and the padded row counts (P_{i-1} = s_i * P_i) ----
