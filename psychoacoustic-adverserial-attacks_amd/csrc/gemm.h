@@ -63,6 +63,10 @@ typedef struct paa_gemm_desc {
     // aux_bf16 != 0: C_pre and aux are bf16 arrays (uint16 bit patterns, same leading dimensions / strides in
     // elements): the pre-activation a GELU product keeps for its backward pass is stored at half the bytes (bf16 mode).
     int32_t aux_bf16;
+    // aux_gate != 0: the array a GELU product keeps for its backward pass holds gelu'(v) instead of v — act GELU writes
+    // C_pre[m,n] = gelu'(v), act GELU_GRAD multiplies by aux[m,n] as it stands.  The derivative is evaluated once, next
+    // to the GELU that shares its exp, instead of again in every backward epilogue (bf16 mode, together with aux_bf16).
+    int32_t aux_gate;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

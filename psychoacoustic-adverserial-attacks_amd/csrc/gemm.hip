@@ -93,11 +93,12 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
                     dead = rem >= d.row_valid;
                 }
                 if (act == PAA_ACT_GELU) {
-                    if (Cpi) Cpi[ci] = dead ? 0.f : v;
-                    if (Cpi16) Cpi16[ci] = dead ? (unsigned short)0 : bf16_bits(v);
+                    const float keep = d.aux_gate ? gelu_grad_f(v) : v;
+                    if (Cpi) Cpi[ci] = dead ? 0.f : keep;
+                    if (Cpi16) Cpi16[ci] = dead ? (unsigned short)0 : bf16_bits(keep);
                     v = gelu_f(v);
                 } else if (act == PAA_ACT_GELU_GRAD) {
-                    v *= gelu_grad_f(ax[e]);
+                    v *= d.aux_gate ? ax[e] : gelu_grad_f(ax[e]);
                 }
                 if (resi) v += resi[dm * ld_res + dn];
                 if (dead) v = 0.f;
@@ -336,6 +337,7 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
     const int64_t cbase = z1 * d.c_s1 + z2 * d.c_s2;
     float* __restrict__ C = d.C ? d.C + cbase : nullptr;
     const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored as bf16
+    const bool gate = d.aux_gate != 0;                  // C_pre / aux hold gelu'(v)
     float* __restrict__ Cp = (d.C_pre && !x16) ? d.C_pre + cbase : nullptr;
     unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + cbase : nullptr;
     unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + cbase : nullptr;
@@ -409,20 +411,29 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = x[k] * alpha + bv[4 * j + k];
             if (act == PAA_ACT_GELU) {
-                if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(x[0], x[1], x[2], x[3]);
-                if (Cp16) {
-                    pp[2 * j] = dead ? 0u : (bf16_bits(x[0]) | ((unsigned)bf16_bits(x[1]) << 16));
-                    pp[2 * j + 1] = dead ? 0u : (bf16_bits(x[2]) | ((unsigned)bf16_bits(x[3]) << 16));
-                }
+                float kp[4];                                  // what the backward pass will want: v, or gelu'(v) (aux_gate)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = FAST ? gelu_fast(x[k]) : gelu_f(x[k]);
+                for (int k = 0; k < 4; ++k) {
+                    if (gate) {
+                        if (FAST) x[k] = gelu_both_fast(x[k], kp[k]);
+                        else { kp[k] = gelu_grad_f(x[k]); x[k] = gelu_f(x[k]); }
+                    } else {
+                        kp[k] = x[k];
+                        x[k] = FAST ? gelu_fast(x[k]) : gelu_f(x[k]);
+                    }
+                }
+                if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kp[0], kp[1], kp[2], kp[3]);
+                if (Cp16) {
+                    pp[2 * j] = dead ? 0u : (bf16_bits(kp[0]) | ((unsigned)bf16_bits(kp[1]) << 16));
+                    pp[2 * j + 1] = dead ? 0u : (bf16_bits(kp[2]) | ((unsigned)bf16_bits(kp[3]) << 16));
+                }
                 if (ex) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) x[k] += e4[k];
                 }
             } else if (gg) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] *= FAST ? gelu_grad_fast(e4[k]) : gelu_grad_f(e4[k]);
+                for (int k = 0; k < 4; ++k) x[k] *= gate ? e4[k] : (FAST ? gelu_grad_fast(e4[k]) : gelu_grad_f(e4[k]));
             } else if (ex) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) x[k] += e4[k];

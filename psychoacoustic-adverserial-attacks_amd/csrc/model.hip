@@ -86,8 +86,9 @@ struct paa_model {
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
     bool fused;                      // flash-style attention kernels (bf16 mode, head_dim 64); else materialised scores
-    bool pre16;                      // bf16 mode: pre-activations kept for GELU backward (L{l}.fpre, and conv{i}.pre, i < last,
-                                     // of the group-norm extractor) are stored as bf16 — they only feed gelu'(.) factors
+    bool pre16;                      // bf16 mode: what a GELU keeps for its backward pass (L{l}.fpre, and conv{i}.pre, i < last,
+                                     // of the group-norm extractor) is stored as bf16 AND as the derivative gelu'(v) itself
+                                     // (paa_gemm_desc.aux_bf16 / aux_gate): it only ever multiplies a gradient
     std::vector<ConvL> conv;
     std::vector<EncL> enc;
     std::map<std::string, std::pair<const float*, int64_t>> tensors;
@@ -323,7 +324,7 @@ static paa_status linear(const paa_model* m, CBf x, CBf w, const float* bias, fl
                          const float* aux = nullptr, bool x16 = false) {
     paa_gemm_desc d = gdb(m, x, w, y, yb, M, N, K, K, K, N);
     d.bias = bias; d.residual = residual; d.ld_res = N; d.act = act; d.C_pre = pre; d.aux = aux; d.ld_aux = N;
-    d.aux_bf16 = x16 ? 1 : 0;
+    d.aux_bf16 = x16 ? 1 : 0; d.aux_gate = d.aux_bf16;     // bf16-stored pre-activations hold gelu'(v)
     return gemm(d, st);
 }
 
@@ -353,7 +354,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             PAA_TRY(layernorm_fwd(c.cv, c.g, c.beta, c.pre, c.row_stats, B * c.P, c.cout, 1e-5f, NOBF, last ? NOBF : c.actb,
                                   last ? c.act_f : nullptr, st));
         } else {
-            d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.act = PAA_ACT_GELU;
+            d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.aux_gate = d.aux_bf16; d.act = PAA_ACT_GELU;
             if (last) d.C = c.act_f; else { d.Cb = c.actb.hi; d.Cb_lo = c.actb.lo; }
             PAA_TRY(gemm(d, st));
         }
@@ -559,7 +560,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             paa_gemm_desc d = gdb(m, ro(m->gH[ji]).off(-(int64_t)Q * c.cout), c.wd[rho], nullptr, NOBF, B * c.P, c.cin, K, c.cout, K, ldo);
             if (out_f32) d.C = m->gF[jo] + (int64_t)rho * c.cin;
             else { Bf o = boff(m->gH[jo], (int64_t)rho * c.cin); d.Cb = o.hi; d.Cb_lo = o.lo; }
-            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0;
+            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_gate = d.aux_bf16;
             d.aux = pr.pre16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(pr.pre) + (int64_t)rho * c.cin)
                              : pr.pre + (int64_t)rho * c.cin;
             PAA_TRY(gemm(d, st));
@@ -633,6 +634,7 @@ extern "C" void paa_abi_sizes(int32_t* out4) {
 }
 
 // Test/diagnostic access to the internal activations (synchronous copy to host as f32; never on the step path).
+// In bf16 mode conv{i}.pre (i < last, group-norm extractor) and L{l}.fpre return gelu'(pre) (see paa_model::pre16).
 // f32 buffers: conv{i}.pre, conv{last}.act, conv{i}.cv, h0, pos_pre, hsum, logits, dlogits, nll, G, gbuf0, dh0, dfn, dxa,
 //              gn_stats, L{l}.qkv|P|ln1_in|fpre|ln2_in.   bf16 planes (hi + lo summed): conv{i}.act (i < last), fn, xfinal.
 extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* host, int64_t max_floats, int B) {

@@ -32,7 +32,7 @@ struct Conv0Args {
     const float* gamma;      // norm affine
     const float* beta;
     float eps;
-    float* pre;              // (B, P, C) norm output (pre-GELU); bf16 storage when pre16 (group-norm forward only)
+    float* pre;              // (B, P, C) norm output (pre-GELU); when pre16 (group-norm forward only): bf16 storage of gelu'(.)
     int pre16;
     Bf actb;                 // (B, P, C) GELU(pre) as bf16 planes (the next conv's GEMM operand)
     float* gn_stats;         // group: (B, C, 2) mean, rstd over time

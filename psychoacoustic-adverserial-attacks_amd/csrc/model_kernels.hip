@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             y[h] = (v[h] - mean[h]) * rstd[h] * gam[h] + bet[h];
-                            g[h] = a.pre16 ? gelu_fast(y[h]) : gelu_f(y[h]);
+                            if (a.pre16) { float dg; g[h] = gelu_both_fast(y[h], dg); y[h] = dg; }       // pre16: keep gelu'(y)
+                            else g[h] = gelu_f(y[h]);
                         }
                         if (a.pre16) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(a.pre) + o) = bf16_bits(y[0]) | ((unsigned)bf16_bits(y[1]) << 16);
                         else *reinterpret_cast<float2*>(a.pre + o) = make_float2(y[0], y[1]);
@@ -258,8 +259,15 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                 const size_t o = ((size_t)b * a.P + t0 + t) * a.C + c;
                 if (MODE == 1) {
                     const float y = (v - mean) * rstd * gam + bet;
-                    if (a.pre16) reinterpret_cast<unsigned short*>(a.pre)[o] = bf16_bits(y); else a.pre[o] = y;
-                    store_bf16(a.actb, o, a.pre16 ? gelu_fast(y) : gelu_f(y));
+                    if (a.pre16) {
+                        float dg;
+                        const float gy = gelu_both_fast(y, dg);
+                        reinterpret_cast<unsigned short*>(a.pre)[o] = bf16_bits(dg);
+                        store_bf16(a.actb, o, gy);
+                    } else {
+                        a.pre[o] = y;
+                        store_bf16(a.actb, o, gelu_f(y));
+                    }
                 } else {
                     float dy = bf16_to_f32(a.dpreb.hi[o]);
                     if (a.dpreb.lo) dy += bf16_to_f32(a.dpreb.lo[o]);

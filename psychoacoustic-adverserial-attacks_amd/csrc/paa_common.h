@@ -103,6 +103,13 @@ __device__ __forceinline__ float gelu_cdf_fast(float x, float& e) {
     return 0.5f * (1.0f + copysignf(erf_abs, x));
 }
 __device__ __forceinline__ float gelu_fast(float x) { float e; return x * gelu_cdf_fast(x, e); }
+// gelu(x) and gelu'(x) together (one exp, one rcp)
+__device__ __forceinline__ float gelu_both_fast(float x, float& dg) {
+    float e;
+    const float cdf = gelu_cdf_fast(x, e);
+    dg = cdf + x * 0.39894228040143268f * e;
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_fast(float x) {
     float e;
     const float cdf = gelu_cdf_fast(x, e);

@@ -21,7 +21,7 @@ def gelu_grad(x):
 DEFAULTS = dict(lda=0, a_kcontig=1, a_kseg=0, a_kseg_stride=0, a_window=0, a_pad=0, a_rows_valid=0, ldb=0, b_kcontig=1,
                 ldc=0, batch=1, batch2=1, a_s1=0, a_s2=0, b_s1=0, b_s2=0, c_s1=0, c_s2=0, alpha=1.0, bias=None, bias_s2=0,
                 act=0, C_pre=None, aux=None, ld_aux=0, aux_s1=0, aux_s2=0, residual=None, ld_res=0, res_s1=0, res_s2=0,
-                row_period=0, row_valid=0, accumulate=0, precision=0)
+                row_period=0, row_valid=0, accumulate=0, precision=0, aux_gate=0)
 
 
 def emulate(d: dict, A: np.ndarray, B: np.ndarray, C: np.ndarray, a_off=0, b_off=0, c_off=0, bias=None, aux=None,
@@ -58,10 +58,11 @@ def emulate(d: dict, A: np.ndarray, B: np.ndarray, C: np.ndarray, a_off=0, b_off
         cidx = co + m * g["ldc"] + n
         if g["act"] == 1:
             if C_pre is not None:
-                C_pre[cidx] = v
+                C_pre[cidx] = gelu_grad(v) if g["aux_gate"] else v
             v = gelu(v)
         elif g["act"] == 2:
-            v = v * gelu_grad(aux[aux_off + z1 * g["aux_s1"] + z2 * g["aux_s2"] + m * g["ld_aux"] + n].astype(np.float64))
+            ax = aux[aux_off + z1 * g["aux_s1"] + z2 * g["aux_s2"] + m * g["ld_aux"] + n].astype(np.float64)
+            v = v * (ax if g["aux_gate"] else gelu_grad(ax))
         if residual is not None:
             v = v + residual[res_off + z1 * g["res_s1"] + z2 * g["res_s2"] + m * g["ld_res"] + n]
         if g["row_period"] > 0:

@@ -106,9 +106,9 @@ def test_gemm_gelu_grad_residual_accumulate(prec):
           dict(A=M * K, B=N * K, C=M * 2 * N, aux=M * 2 * N, residual=M * N), prec, offs=dict(C=N, aux=N))
 
 
-def _bf_case(name, d, shapes, prec, seed=0, offs=None, x16=False):
+def _bf_case(name, d, shapes, prec, seed=0, offs=None, x16=False, gate=False):
     """bf16-operand path: A / B are bf16 planes (hi [+ lo]); the reference multiplies exactly those values.
-    x16: C_pre / aux are bf16 arrays (aux_bf16 = 1)."""
+    x16: C_pre / aux are bf16 arrays (aux_bf16 = 1); gate: they hold gelu'(v) (aux_gate = 1)."""
     from paa_amd.model import bf16_bits, bf16_to_f32, split_bf16
     rng = np.random.default_rng(seed)
     host = {k: rng.normal(size=n).astype(np.float32) for k, n in shapes.items()}
@@ -131,7 +131,7 @@ def _bf_case(name, d, shapes, prec, seed=0, offs=None, x16=False):
     cbl = torch.zeros(shapes["C"], dtype=torch.int16, device="cuda")
     bufs["Cb"], bufs["Cb_lo"] = cb, cbl
     dd = dict(d)
-    dd.update(precision=prec, operand_bf16=1, aux_bf16=int(x16))
+    dd.update(precision=prec, operand_bf16=1, aux_bf16=int(x16), aux_gate=int(gate))
     names = {k: k for k in shapes}
     names.update(Cb="Cb")
     if prec:
@@ -157,7 +157,8 @@ def _bf_case(name, d, shapes, prec, seed=0, offs=None, x16=False):
     print(f"gemm_bf[{name}] prec={prec} x16={int(x16)} rel_err={e:.3e} bf16-planes rel_err={eb:.3e} C_pre rel_err={ep:.3e}")
     assert e < (3e-5 if prec else 5e-6), name
     assert eb < (3e-5 if prec else 5e-3), name
-    assert ep < (5e-3 if x16 else (3e-5 if prec else 5e-6)), name
+    # a kept gelu'(v) inherits the product's error scaled by max|v| / max|gelu'| (~30x here)
+    assert ep < (5e-3 if x16 else (3e-4 if gate else (3e-5 if prec else 5e-6))), name
 
 
 @pytest.mark.parametrize("prec", [0, 1])
@@ -194,6 +195,11 @@ def test_gemm_bf16_operands(prec):
     _bf_case("tallM_pre16", dict(M=2500, N=200, K=320, lda=320, ldb=320, ldc=200, act=1), dict(A=2500 * 320, B=200 * 320, C=2500 * 200, bias=200, C_pre=2500 * 200), prec, x16=True)
     _bf_case("tallM_aux16", dict(M=2400, N=256, K=128, lda=128, ldb=128, ldc=256, act=2, ld_aux=256), dict(A=2400 * 128, B=256 * 128, C=2400 * 256, aux=2400 * 256), prec, x16=True)
     _bf_case("small_pre16", dict(M=300, N=100, K=96, lda=96, ldb=96, ldc=100, act=1), dict(A=300 * 96, B=100 * 96, C=300 * 100, bias=100, C_pre=300 * 100), prec, x16=True)
+    # ... holding gelu'(v) instead of v (aux_gate): vector and scalar epilogues, both directions
+    _bf_case("tallM_gate_fwd", dict(M=2500, N=200, K=320, lda=320, ldb=320, ldc=200, act=1), dict(A=2500 * 320, B=200 * 320, C=2500 * 200, bias=200, C_pre=2500 * 200), prec, x16=True, gate=True)
+    _bf_case("tallM_gate_bwd", dict(M=2400, N=256, K=128, lda=128, ldb=128, ldc=256, act=2, ld_aux=256), dict(A=2400 * 128, B=256 * 128, C=2400 * 256, aux=2400 * 256), prec, x16=True, gate=True)
+    _bf_case("small_gate_fwd", dict(M=300, N=100, K=96, lda=96, ldb=96, ldc=100, act=1), dict(A=300 * 96, B=100 * 96, C=300 * 100, bias=100, C_pre=300 * 100), prec, x16=True, gate=True)
+    _bf_case("small_gate_f32", dict(M=300, N=100, K=96, lda=96, ldb=96, ldc=100, act=1), dict(A=300 * 96, B=100 * 96, C=300 * 100, bias=100, C_pre=300 * 100), prec, gate=True)
     _bf_case("dgrad_aux16", dict(M=Mr, N=Ci, K=2 * Co, lda=Co, ldb=2 * Co, ldc=2 * Ci, act=2, ld_aux=2 * Ci),
              dict(A=(Mr + 8) * Co, B=Ci * 2 * Co, C=Mr * 2 * Ci, aux=Mr * 2 * Ci), prec, offs=dict(A=7 * Co, C=Ci, aux=Ci), x16=True)
 
