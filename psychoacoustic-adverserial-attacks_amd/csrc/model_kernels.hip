@@ -44,14 +44,13 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
         o[3] = (v.w - mean) * rstd * gg.w + bv.w;
         const size_t i0 = (size_t)row * cols + c;
         if (y) *reinterpret_cast<float4*>(y + i0) = make_float4(o[0], o[1], o[2], o[3]);
+        store_bf16x4(yb, i0, o);
+        if (actb.hi || yact) {
+            float ga[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            store_bf16(yb, i0 + j, o[j]);
-            if (actb.hi || yact) {
-                const float ga = gelu_f(o[j]);
-                store_bf16(actb, i0 + j, ga);
-                if (yact) yact[i0 + j] = ga;
-            }
+            for (int j = 0; j < 4; ++j) ga[j] = gelu_f(o[j]);
+            store_bf16x4(actb, i0, ga);
+            if (yact) *reinterpret_cast<float4*>(yact + i0) = make_float4(ga[0], ga[1], ga[2], ga[3]);
         }
     }
 }
@@ -67,23 +66,44 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     const size_t o = (size_t)row * cols;
     const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < cols; c += 64) {
-        float d = dy[o + c];
-        if (gelu_pre) d *= gelu_grad_f(gelu_pre[o + c]);
-        const float gd = g[c] * d;
-        s1 += gd;
-        s2 += gd * ((x[o + c] - mean) * rstd);
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 d4 = *reinterpret_cast<const float4*>(dy + o + c);
+        const float4 x4 = *reinterpret_cast<const float4*>(x + o + c);
+        const float4 g4 = *reinterpret_cast<const float4*>(g + c);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        if (gelu_pre) {
+            const float4 p4 = *reinterpret_cast<const float4*>(gelu_pre + o + c);
+            d[0] *= gelu_grad_f(p4.x); d[1] *= gelu_grad_f(p4.y); d[2] *= gelu_grad_f(p4.z); d[3] *= gelu_grad_f(p4.w);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gd = gv[j] * d[j];
+            s1 += gd;
+            s2 += gd * ((xv[j] - mean) * rstd);
+        }
     }
     s1 = wave_sum(s1) / (float)cols;
     s2 = wave_sum(s2) / (float)cols;
-    for (int c = lane; c < cols; c += 64) {
-        float d = dy[o + c];
-        if (gelu_pre) d *= gelu_grad_f(gelu_pre[o + c]);
-        const float xh = (x[o + c] - mean) * rstd;
-        float v = rstd * (g[c] * d - s1 - xh * s2);
-        if (add) v += add[o + c];
-        if (dx) dx[o + c] = v;
-        store_bf16(dxb, o + c, v);
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 d4 = *reinterpret_cast<const float4*>(dy + o + c);
+        const float4 x4 = *reinterpret_cast<const float4*>(x + o + c);
+        const float4 g4 = *reinterpret_cast<const float4*>(g + c);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        if (gelu_pre) {
+            const float4 p4 = *reinterpret_cast<const float4*>(gelu_pre + o + c);
+            d[0] *= gelu_grad_f(p4.x); d[1] *= gelu_grad_f(p4.y); d[2] *= gelu_grad_f(p4.z); d[3] *= gelu_grad_f(p4.w);
+        }
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rstd * (gv[j] * d[j] - s1 - ((xv[j] - mean) * rstd) * s2);
+        if (add) {
+            const float4 a4 = *reinterpret_cast<const float4*>(add + o + c);
+            v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+        }
+        if (dx) *reinterpret_cast<float4*>(dx + o + c) = make_float4(v[0], v[1], v[2], v[3]);
+        store_bf16x4(dxb, o + c, v);
     }
 }
 
@@ -97,6 +117,7 @@ paa_status layernorm_fwd(const float* x, const float* g, const float* b, float* 
 
 paa_status layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, const float* add,
                          const float* gelu_pre, float* dx, Bf dxb, int rows, int cols, hipStream_t st) {
+    if (cols & 3) PAA_FAIL(PAA_ERR_ARG, "layernorm backward: cols=%d must be a multiple of 4", cols);
     hipLaunchKernelGGL(k_ln_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, x, g, stats, add, gelu_pre, dx, rows, cols, dxb);
     PAA_LAUNCH_CHECK();
     return PAA_OK;

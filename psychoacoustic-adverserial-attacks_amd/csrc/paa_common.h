@@ -83,6 +83,21 @@ __device__ __forceinline__ void store_bf16(const Bf& o, size_t i, float v) {
     }
 }
 
+// four consecutive values -> bf16 planes, one 8-byte store per plane (i multiple of 4)
+__device__ __forceinline__ void store_bf16x4(const Bf& o, size_t i, const float (&v)[4]) {
+    if (!o.hi) return;
+    unsigned h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = bf16_bits(v[j]);
+    *reinterpret_cast<uint2*>(o.hi + i) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    if (o.lo) {
+        unsigned l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l[j] = bf16_bits(v[j] - __uint_as_float(h[j] << 16));
+        *reinterpret_cast<uint2*>(o.lo + i) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+}
+
 // exact (erf) GELU and its derivative, as torch.nn.functional.gelu(approximate='none')
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
