@@ -111,7 +111,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // e = exp(-x^2 / 2) is shared between erf(x / sqrt 2) and the normal pdf of the derivative.
 __device__ __forceinline__ float gelu_cdf_fast(float x, float& e) {
     const float ax = fabsf(x) * 0.70710678118654752f;
-    e = __expf(-ax * ax);
+    e = __builtin_amdgcn_exp2f(-1.44269504088896341f * ax * ax);     // raw v_exp_f32: the argument is <= 0, underflow -> 0
     const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * e;
