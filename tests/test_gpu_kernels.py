@@ -244,7 +244,10 @@ def test_softmax_fwd_bwd():
     assert float(sd[:, cols:].abs().max()) == 0 and float(dpd[:, cols:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("T,S_max,lens", [(24, 6, [5, 6, 3, 0]), (499, 150, [150, 120, 1, 77]), (60, 30, [30, 29, 30, 2])])
+# label capacities: 2 S_max + 1 <= 1024 -> wave-synchronous probability-domain kernels (1, 2, 6, 16 states per lane);
+# (700, 600): the log-domain kernel for larger capacities; (60, 30, [.., 40->infeasible]) is covered by lens > T below
+@pytest.mark.parametrize("T,S_max,lens", [(24, 6, [5, 6, 3, 0]), (499, 150, [150, 120, 1, 77]), (60, 30, [30, 29, 30, 2]),
+                                          (80, 40, [40, 1, 33, 40]), (499, 499, [300, 150, 499, 250]), (700, 600, [600, 150, 20, 333])])
 def test_ctc(T, S_max, lens):
     torch.manual_seed(2)
     B, V = len(lens), 32
