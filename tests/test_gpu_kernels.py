@@ -112,7 +112,8 @@ def _bf_case(name, d, shapes, prec, seed=0, offs=None, x16=False, gate=False):
     from paa_amd.model import bf16_bits, bf16_to_f32, split_bf16
     rng = np.random.default_rng(seed)
     host = {k: rng.normal(size=n).astype(np.float32) for k, n in shapes.items()}
-    host["C"][:] = 0
+    if not d.get("accumulate"):
+        host["C"][:] = 0
     bufs, ref = {}, {}
     for k, v in host.items():
         if k in ("A", "B"):
@@ -195,6 +196,9 @@ def test_gemm_bf16_operands(prec):
     _bf_case("tallM_pre16", dict(M=2500, N=200, K=320, lda=320, ldb=320, ldc=200, act=1), dict(A=2500 * 320, B=200 * 320, C=2500 * 200, bias=200, C_pre=2500 * 200), prec, x16=True)
     _bf_case("tallM_aux16", dict(M=2400, N=256, K=128, lda=128, ldb=128, ldc=256, act=2, ld_aux=256), dict(A=2400 * 128, B=256 * 128, C=2400 * 256, aux=2400 * 256), prec, x16=True)
     _bf_case("small_pre16", dict(M=300, N=100, K=96, lda=96, ldb=96, ldc=100, act=1), dict(A=300 * 96, B=100 * 96, C=300 * 100, bias=100, C_pre=300 * 100), prec, x16=True)
+    # accumulate into a non-zero C with a residual: vector and scalar epilogues
+    _bf_case("tallM_accum", dict(M=2500, N=256, K=128, lda=128, ldb=128, ldc=256, ld_res=256, accumulate=1), dict(A=2500 * 128, B=256 * 128, C=2500 * 256, residual=2500 * 256), prec)
+    _bf_case("small_accum", dict(M=300, N=100, K=96, lda=96, ldb=96, ldc=100, ld_res=100, accumulate=1), dict(A=300 * 96, B=100 * 96, C=300 * 100, residual=300 * 100), prec)
     # ... holding gelu'(v) instead of v (aux_gate): vector and scalar epilogues, both directions
     _bf_case("tallM_gate_fwd", dict(M=2500, N=200, K=320, lda=320, ldb=320, ldc=200, act=1), dict(A=2500 * 320, B=200 * 320, C=2500 * 200, bias=200, C_pre=2500 * 200), prec, x16=True, gate=True)
     _bf_case("tallM_gate_bwd", dict(M=2400, N=256, K=128, lda=128, ldb=128, ldc=256, act=2, ld_aux=256), dict(A=2400 * 128, B=256 * 128, C=2400 * 256, aux=2400 * 256), prec, x16=True, gate=True)
