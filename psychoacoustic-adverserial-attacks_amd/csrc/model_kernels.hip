@@ -204,16 +204,15 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
     // backward pass, the 4 gradient loads are issued together so that enough bytes are in flight to cover HBM latency.
     if (a.stride == 5 && a.k == 10 && (a.C & 1) == 0) {
         for (int c = 2 * threadIdx.x; c < a.C; c += 512) {
-            float w[2][10], mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f}, gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
-            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+            // the channel pair rides in 2-wide vectors: v_pk_fma_f32 does both channels' multiply-adds at once
+            f32x2 w2[10], mean2, rstd2, gam2, bet2;
+            f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int j = 0; j < 10; ++j) w[h][j] = a.w[(c + h) * 10 + j];
-                mean[h] = a.gn_stats[((size_t)b * a.C + c + h) * 2];
-                rstd[h] = a.gn_stats[((size_t)b * a.C + c + h) * 2 + 1];
-                gam[h] = a.gamma[c + h]; bet[h] = a.beta[c + h];
-            }
+            for (int j = 0; j < 10; ++j) w2[j] = f32x2{a.w[c * 10 + j], a.w[(c + 1) * 10 + j]};
+            mean2 = f32x2{a.gn_stats[((size_t)b * a.C + c) * 2], a.gn_stats[((size_t)b * a.C + c + 1) * 2]};
+            rstd2 = f32x2{a.gn_stats[((size_t)b * a.C + c) * 2 + 1], a.gn_stats[((size_t)b * a.C + c + 1) * 2 + 1]};
+            gam2 = f32x2{a.gamma[c], a.gamma[c + 1]};
+            bet2 = f32x2{a.beta[c], a.beta[c + 1]};
             for (int t = 0; t < nt; t += 4) {
                 unsigned dh[4] = {0u, 0u, 0u, 0u}, dl4[4] = {0u, 0u, 0u, 0u};
                 if (MODE == 2) {
@@ -235,34 +234,34 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                 for (int f = 0; f < 4; ++f) {
                     if (t + f >= nt) continue;
                     const size_t o = ((size_t)b * a.P + t0 + t + f) * a.C + c;
-                    float v[2] = {0.f, 0.f};
+                    f32x2 v = {0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < 10; ++j) { v[0] += w[0][j] * xw[5 * f + j]; v[1] += w[1][j] * xw[5 * f + j]; }
+                    for (int j = 0; j < 10; ++j) v += w2[j] * xw[5 * f + j];
                     if (MODE == 1) {
-                        float y[2], g[2];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            y[h] = (v[h] - mean[h]) * rstd[h] * gam[h] + bet[h];
-                            if (a.pre16) { float dg; g[h] = gelu_both_fast(y[h], dg); y[h] = dg; }       // pre16: keep gelu'(y)
-                            else g[h] = gelu_f(y[h]);
+                        f32x2 y = (v - mean2) * rstd2 * gam2 + bet2, g;
+                        if (a.pre16) {                       // bf16 mode: keep gelu'(y) as bf16
+                            f32x2 dg;
+                            g = gelu_both_fast2(y, dg);
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(a.pre) + o) = bf16_bits(dg.x) | ((unsigned)bf16_bits(dg.y) << 16);
+                        } else {
+                            g = f32x2{gelu_f(y.x), gelu_f(y.y)};
+                            *reinterpret_cast<float2*>(a.pre + o) = make_float2(y.x, y.y);
                         }
-                        if (a.pre16) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(a.pre) + o) = bf16_bits(y[0]) | ((unsigned)bf16_bits(y[1]) << 16);
-                        else *reinterpret_cast<float2*>(a.pre + o) = make_float2(y[0], y[1]);
-                        const unsigned short h0 = bf16_bits(g[0]), h1 = bf16_bits(g[1]);
+                        const unsigned short h0 = bf16_bits(g.x), h1 = bf16_bits(g.y);
                         *reinterpret_cast<unsigned*>(a.actb.hi + o) = h0 | ((unsigned)h1 << 16);
                         if (a.actb.lo)
-                            *reinterpret_cast<unsigned*>(a.actb.lo + o) = bf16_bits(g[0] - bf16_to_f32(h0)) | ((unsigned)bf16_bits(g[1] - bf16_to_f32(h1)) << 16);
+                            *reinterpret_cast<unsigned*>(a.actb.lo + o) = bf16_bits(g.x - bf16_to_f32(h0)) | ((unsigned)bf16_bits(g.y - bf16_to_f32(h1)) << 16);
                     } else {
-                        const float dy0 = __uint_as_float(dh[f] << 16) + __uint_as_float(dl4[f] << 16);
-                        const float dy1 = __uint_as_float(dh[f] & 0xFFFF0000u) + __uint_as_float(dl4[f] & 0xFFFF0000u);
-                        s1[0] += dy0; s2[0] += dy0 * ((v[0] - mean[0]) * rstd[0]);
-                        s1[1] += dy1; s2[1] += dy1 * ((v[1] - mean[1]) * rstd[1]);
+                        const f32x2 dy = {__uint_as_float(dh[f] << 16) + __uint_as_float(dl4[f] << 16),
+                                          __uint_as_float(dh[f] & 0xFFFF0000u) + __uint_as_float(dl4[f] & 0xFFFF0000u)};
+                        s1 += dy;
+                        s2 += dy * ((v - mean2) * rstd2);
                     }
                 }
             }
             if (MODE != 1) {
                 const size_t o = (((size_t)b * gridDim.x + chunk) * a.C + c) * 2;
-                *reinterpret_cast<float4*>(a.part + o) = make_float4(s1[0], s2[0], s1[1], s2[1]);
+                *reinterpret_cast<float4*>(a.part + o) = make_float4(s1.x, s2.x, s1.y, s2.y);
             }
         }
     } else {

@@ -131,4 +131,22 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     return cdf + x * 0.39894228040143268f * e;
 }
 
+// two values at once (v_pk_fma_f32 / v_pk_mul_f32 carry the polynomial; exp and rcp stay scalar): same arithmetic as
+// gelu_both_fast per component
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_both_fast2(f32x2 x, f32x2& dg) {
+    f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    ax = ax * 0.70710678118654752f;
+    const f32x2 q = -1.44269504088896341f * ax * ax;
+    const f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    const f32x2 den = 1.0f + 0.3275911f * ax;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2 ea = 1.0f - poly * e;
+    const f32x2 er = {copysignf(ea.x, x.x), copysignf(ea.y, x.y)};
+    const f32x2 cdf = 0.5f * (1.0f + er);
+    dg = cdf + x * 0.39894228040143268f * e;
+    return x * cdf;
+}
+
 }  // namespace paa
