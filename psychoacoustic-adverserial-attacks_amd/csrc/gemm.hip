@@ -412,14 +412,19 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
             for (int k = 0; k < 4; ++k) x[k] = x[k] * alpha + bv[4 * j + k];
             if (act == PAA_ACT_GELU) {
                 float kp[4];                                  // what the backward pass will want: v, or gelu'(v) (aux_gate)
+                if (FAST) {                                   // two values per packed-math GELU
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (gate) {
-                        if (FAST) x[k] = gelu_both_fast(x[k], kp[k]);
-                        else { kp[k] = gelu_grad_f(x[k]); x[k] = gelu_f(x[k]); }
-                    } else {
-                        kp[k] = x[k];
-                        x[k] = FAST ? gelu_fast(x[k]) : gelu_f(x[k]);
+                    for (int k = 0; k < 4; k += 2) {
+                        f32x2 dg;
+                        const f32x2 gv = gelu_both_fast2(f32x2{x[k], x[k + 1]}, dg);
+                        kp[k] = gate ? dg.x : x[k]; kp[k + 1] = gate ? dg.y : x[k + 1];
+                        x[k] = gv.x; x[k + 1] = gv.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        kp[k] = gate ? gelu_grad_f(x[k]) : x[k];
+                        x[k] = gelu_f(x[k]);
                     }
                 }
                 if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kp[0], kp[1], kp[2], kp[3]);
