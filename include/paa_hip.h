@@ -155,6 +155,12 @@ paa_status paa_prof_read(double* out192);
 paa_status paa_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int P, int Tp, int H, int nh, void* stream);
 paa_status paa_attn_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, float* delta, void* dqkv,
                         int B, int T, int P, int Tp, int H, int nh, void* stream);
+/* the same with every operand as a hi + lo pair of bf16 planes (split-bf16, the fp32-parity mode) */
+paa_status paa_attn_fwd_split(const void* qkv_hi, const void* qkv_lo, void* ctx_hi, void* ctx_lo, float* lse, int B, int T, int P,
+                              int Tp, int H, int nh, void* stream);
+paa_status paa_attn_bwd_split(const void* qkv_hi, const void* qkv_lo, const void* ctx_hi, const void* ctx_lo, const float* lse,
+                              const void* dctx_hi, const void* dctx_lo, float* delta, void* dqkv_hi, void* dqkv_lo,
+                              int B, int T, int P, int Tp, int H, int nh, void* stream);
 paa_status paa_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* stats,
                              int rows, int cols, float eps, void* stream);
 paa_status paa_layernorm_bwd(const float* dy, const float* x, const float* g, const float* stats, float* dx,

@@ -83,6 +83,8 @@ _SIGS = {
     "paa_prof_read": (C.c_int, [C.c_void_p]),
     "paa_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "paa_attn_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]),
+    "paa_attn_fwd_split": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
+    "paa_attn_bwd_split": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 6 + [C.c_void_p]),
     "paa_layernorm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "paa_layernorm_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p]),
     "paa_softmax_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),

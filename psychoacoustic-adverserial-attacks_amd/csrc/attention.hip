@@ -16,6 +16,7 @@
 //   forward, dQ : own = queries, other = keys          dK/dV : own = keys, other = queries
 // Exponentials are raw v_exp_f32 (arguments are <= 8 and flush to 0 far below: no denormal-range fix-up needed).
 // Q/K/V/dO are rows of the (M, 3H) / (M, H) bf16 planes the GEMM epilogues write; outputs go back as bf16.
+// PREC = 1 (fp32-parity mode): every operand is a hi + lo pair of planes and every product three MFMA passes.
 #include "model_kernels.h"
 
 namespace paa {
@@ -115,13 +116,55 @@ __device__ __forceinline__ void attn_block(int nb, int nheads, int& bh, int& ob)
     }
 }
 
+// split-bf16 helpers (PREC = 1, the fp32-parity mode): every operand is a hi + lo pair of bf16 planes and a product is
+// three MFMA passes, lo*hi + hi*lo + hi*hi — the same scheme as the GEMM kernels
+template <int PREC>
+__device__ __forceinline__ f32x16 mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 acc) {
+    if constexpr (PREC) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+// bf16 hi (and lo = bf16(v - hi)) packs of accumulator registers 8 s2 .. 8 s2 + 7
+template <int PREC, typename V>
+__device__ __forceinline__ void pack8s(const V& v, int s2, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned short h = bf16_bits(v[8 * s2 + j]);
+        hi[j] = (short)h;
+        if constexpr (PREC) lo[j] = (short)bf16_bits(v[8 * s2 + j] - bf16_to_f32(h));
+    }
+}
+// write the transposed accumulators acc[dt][e] * mul as bf16 rows into the hi (and lo) plane
+template <int PREC>
+__device__ __forceinline__ void store_own_s(unsigned short* __restrict__ dh, unsigned short* __restrict__ dl, int64_t ld, int row,
+                                            int lh, const f32x16 (&acc)[2], float mul) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = dt * 32 + 8 * g4 + 4 * lh;
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = acc[dt][4 * g4 + k] * mul;
+                h[k] = bf16_bits(v);
+                l[k] = PREC ? bf16_bits(v - __uint_as_float(h[k] << 16)) : 0u;
+            }
+            *reinterpret_cast<uint2*>(dh + (int64_t)row * ld + d) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            if constexpr (PREC) *reinterpret_cast<uint2*>(dl + (int64_t)row * ld + d) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // 64 keys per iteration (two 32-key score tiles), K / V tiles double-buffered in LDS and prefetched through registers:
-// one barrier per 64 keys, 16 MFMAs per wave between barriers.
+// one barrier per 64 keys, 16 (x3 in split mode) MFMAs per wave between barriers.
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnArgs a) {
-    constexpr int KT = 64;
-    __shared__ __attribute__((aligned(16))) unsigned short sK[2][KT * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sV[2][KT * AT_RM];
+    constexpr int KT = 64, NPL = PREC ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short sK[NPL][2][KT * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sV[NPL][2][KT * AT_RM];
     int bh, oblk;
     attn_block((a.T + 127) / 128, a.nbh, bh, oblk);
     const int b = bh / a.nh, h = bh - b * a.nh;
@@ -129,36 +172,47 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnArgs a) {
     const int q = oblk * 128 + wave * 32 + lr;
     const int qc = q < a.T ? q : a.T - 1;
     const int64_t ld = 3 * (int64_t)a.H;
-    const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
-    bf16x8 qf[4];
-    load_own(base, ld, qc, lh, qf);
+    const int64_t hoff = (int64_t)b * a.P * ld + h * AT_D;
+    const unsigned short* base[2] = {a.qkv + hoff, PREC ? a.qkv_lo + hoff : nullptr};
+    bf16x8 qf[NPL][4];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) load_own(base[pl], ld, qc, lh, qf[pl]);
     const float c = a.scale * 1.44269504088896341f;
     float m = -INFINITY, l = 0.f;
     f32x16 o[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
     const int nt = (a.T + KT - 1) / KT;
-    uint4 rk[KT / 32], rv[KT / 32];
-    tile_load<KT>(base + a.H, ld, 0, a.T, rk);
-    tile_load<KT>(base + 2 * a.H, ld, 0, a.T, rv);
-    tile_store<KT>(sK[0], rk);
-    tile_store<KT>(sV[0], rv);
+    uint4 rk[NPL][KT / 32], rv[NPL][KT / 32];
+    auto tload = [&](int kt) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            tile_load<KT>(base[pl] + a.H, ld, kt * KT, a.T, rk[pl]);
+            tile_load<KT>(base[pl] + 2 * a.H, ld, kt * KT, a.T, rv[pl]);
+        }
+    };
+    auto tstore = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { tile_store<KT>(sK[pl][buf], rk[pl]); tile_store<KT>(sV[pl][buf], rv[pl]); }
+    };
+    tload(0);
+    tstore(0);
     __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
-        const unsigned short* cK = sK[kt & 1];
-        const unsigned short* cV = sV[kt & 1];
-        if (kt + 1 < nt) {
-            tile_load<KT>(base + a.H, ld, (kt + 1) * KT, a.T, rk);
-            tile_load<KT>(base + 2 * a.H, ld, (kt + 1) * KT, a.T, rv);
-        }
+        const int cb = kt & 1;
+        if (kt + 1 < nt) tload(kt + 1);
         f32x16 s[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(cK + u * 32 * AT_RM, lr, lh, ks), qf[ks], s[u], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kh = frag_rm(sK[0][cb] + u * 32 * AT_RM, lr, lh, ks);
+                bf16x8 kl = kh;
+                if constexpr (PREC) kl = frag_rm(sK[NPL - 1][cb] + u * 32 * AT_RM, lr, lh, ks);
+                s[u] = mma3<PREC>(kh, kl, qf[0][ks], qf[NPL - 1][ks], s[u]);
+            }
         }
         // Online softmax on the raw scores (scale folded into the exponent's FMA).  The running maximum is only
         // raised — and l, O rescaled — when some row of the wave exceeds it by more than 2^8: exp2 of a bounded
@@ -197,28 +251,33 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnArgs a) {
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pb = pack8v(s[u], s2);
+                bf16x8 ph, pl_;
+                pack8s<PREC>(s[u], s2, ph, pl_);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(cV + u * 32 * AT_RM, lr, lh, dt, s2), pb, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 vh = frag_tr(sV[0][cb] + u * 32 * AT_RM, lr, lh, dt, s2);
+                    bf16x8 vl = vh;
+                    if constexpr (PREC) vl = frag_tr(sV[NPL - 1][cb] + u * 32 * AT_RM, lr, lh, dt, s2);
+                    o[dt] = mma3<PREC>(vh, vl, ph, pl_, o[dt]);
+                }
             }
-        if (kt + 1 < nt) {
-            tile_store<KT>(sK[(kt + 1) & 1], rk);
-            tile_store<KT>(sV[(kt + 1) & 1], rv);
-        }
+        if (kt + 1 < nt) tstore((kt + 1) & 1);
         __syncthreads();
     }
     if (q < a.T) {
-        store_own(a.ctx + (int64_t)b * a.P * a.H + h * AT_D, a.H, q, lh, o, 1.f / l);
+        const int64_t co = (int64_t)b * a.P * a.H + h * AT_D;
+        store_own_s<PREC>(a.ctx + co, PREC ? a.ctx_lo + co : nullptr, a.H, q, lh, o, 1.f / l);
         if (lh == 0) a.lse[(int64_t)bh * a.Tp + q] = m + log2f(l);
     }
 }
 
 // ------------------------------------------------------------------------------------- backward: dQ
 // own = queries.  Also computes delta = rowsum(dO * O) and stores it for the dK/dV kernel.
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sKb[2][32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sVb[2][32 * AT_RM];
+    constexpr int NPL = PREC ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short sKb[NPL][2][32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sVb[NPL][2][32 * AT_RM];
     int bh, oblk;
     attn_block((a.T + 127) / 128, a.nbh, bh, oblk);
     const int b = bh / a.nh, h = bh - b * a.nh;
@@ -226,18 +285,29 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(AttnArgs a) {
     const int q = oblk * 128 + wave * 32 + lr;
     const int qc = q < a.T ? q : a.T - 1;
     const int64_t ld = 3 * (int64_t)a.H;
-    const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
-    const unsigned short* dob = a.dctx + (int64_t)b * a.P * a.H + h * AT_D;
-    const unsigned short* ob = a.ctx + (int64_t)b * a.P * a.H + h * AT_D;
-    bf16x8 qf[4], dof[4], of[4];
-    load_own(base, ld, qc, lh, qf);
-    load_own(dob, a.H, qc, lh, dof);
-    load_own(ob, a.H, qc, lh, of);
+    const int64_t hoff = (int64_t)b * a.P * ld + h * AT_D, coff = (int64_t)b * a.P * a.H + h * AT_D;
+    const unsigned short* base[2] = {a.qkv + hoff, PREC ? a.qkv_lo + hoff : nullptr};
+    const unsigned short* dob[2] = {a.dctx + coff, PREC ? a.dctx_lo + coff : nullptr};
+    const unsigned short* ob[2] = {a.ctx + coff, PREC ? a.ctx_lo + coff : nullptr};
+    bf16x8 qf[NPL][4], dof[NPL][4];
     float delta = 0.f;
+    {
+        bf16x8 of[NPL][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int pl = 0; pl < NPL; ++pl) {
+            load_own(base[pl], ld, qc, lh, qf[pl]);
+            load_own(dob[pl], a.H, qc, lh, dof[pl]);
+            load_own(ob[pl], a.H, qc, lh, of[pl]);
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) delta += bf16_to_f32((unsigned short)dof[s][j]) * bf16_to_f32((unsigned short)of[s][j]);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float dv = bf16_to_f32((unsigned short)dof[0][s][j]), ov = bf16_to_f32((unsigned short)of[0][s][j]);
+                if constexpr (PREC) { dv += bf16_to_f32((unsigned short)dof[NPL - 1][s][j]); ov += bf16_to_f32((unsigned short)of[NPL - 1][s][j]); }
+                delta += dv * ov;
+            }
+    }
     delta += __shfl_xor(delta, 32, 64);
     const float lse = a.lse[(int64_t)bh * a.Tp + qc];
     if (q < a.T && lh == 0) a.delta[(int64_t)bh * a.Tp + q] = delta;
@@ -246,26 +316,34 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
     const int nt = (a.T + 31) / 32;
-    uint4 rk[1], rv[1];
-    tile_load<32>(base + a.H, ld, 0, a.T, rk);
-    tile_load<32>(base + 2 * a.H, ld, 0, a.T, rv);
-    tile_store<32>(sKb[0], rk);
-    tile_store<32>(sVb[0], rv);
+    uint4 rk[NPL][1], rv[NPL][1];
+    auto tload = [&](int kt) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            tile_load<32>(base[pl] + a.H, ld, kt * 32, a.T, rk[pl]);
+            tile_load<32>(base[pl] + 2 * a.H, ld, kt * 32, a.T, rv[pl]);
+        }
+    };
+    auto tstore = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { tile_store<32>(sKb[pl][buf], rk[pl]); tile_store<32>(sVb[pl][buf], rv[pl]); }
+    };
+    tload(0);
+    tstore(0);
     __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
-        const unsigned short* sK = sKb[kt & 1];
-        const unsigned short* sV = sVb[kt & 1];
-        if (kt + 1 < nt) {
-            tile_load<32>(base + a.H, ld, (kt + 1) * 32, a.T, rk);
-            tile_load<32>(base + 2 * a.H, ld, (kt + 1) * 32, a.T, rv);
-        }
+        const int cb = kt & 1;
+        if (kt + 1 < nt) tload(kt + 1);
         f32x16 s, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sK, lr, lh, ks), qf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sV, lr, lh, ks), dof[ks], dp, 0, 0, 0);
+            const bf16x8 kh = frag_rm(sKb[0][cb], lr, lh, ks), vh = frag_rm(sVb[0][cb], lr, lh, ks);
+            bf16x8 kl = kh, vl = vh;
+            if constexpr (PREC) { kl = frag_rm(sKb[NPL - 1][cb], lr, lh, ks); vl = frag_rm(sVb[NPL - 1][cb], lr, lh, ks); }
+            s = mma3<PREC>(kh, kl, qf[0][ks], qf[NPL - 1][ks], s);
+            dp = mma3<PREC>(vh, vl, dof[0][ks], dof[NPL - 1][ks], dp);
         }
         float ds[16];                                        // dS / scale (the scale multiplies dQ once, at the end)
 #pragma unroll
@@ -277,24 +355,29 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq(AttnArgs a) {
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 db = pack8(ds, s2);
+            bf16x8 dh, dl;
+            pack8s<PREC>(ds, s2, dh, dl);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sK, lr, lh, dt, s2), db, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 kh = frag_tr(sKb[0][cb], lr, lh, dt, s2);
+                bf16x8 kl = kh;
+                if constexpr (PREC) kl = frag_tr(sKb[NPL - 1][cb], lr, lh, dt, s2);
+                dq[dt] = mma3<PREC>(kh, kl, dh, dl, dq[dt]);
+            }
         }
-        if (kt + 1 < nt) {
-            tile_store<32>(sKb[(kt + 1) & 1], rk);
-            tile_store<32>(sVb[(kt + 1) & 1], rv);
-        }
+        if (kt + 1 < nt) tstore((kt + 1) & 1);
         __syncthreads();
     }
-    if (q < a.T) store_own(a.dqkv + (int64_t)b * a.P * ld + h * AT_D, ld, q, lh, dq, a.scale);
+    if (q < a.T) store_own_s<PREC>(a.dqkv + hoff, PREC ? a.dqkv_lo + hoff : nullptr, ld, q, lh, dq, a.scale);
 }
 
 // ---------------------------------------------------------------------------------- backward: dK, dV
 // own = keys (lanes), other = queries (accumulator rows).
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short sQb[2][32 * AT_RM];
-    __shared__ __attribute__((aligned(16))) unsigned short sdOb[2][32 * AT_RM];
+    constexpr int NPL = PREC ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short sQb[NPL][2][32 * AT_RM];
+    __shared__ __attribute__((aligned(16))) unsigned short sdOb[NPL][2][32 * AT_RM];
     __shared__ float sLseb[2][32], sDelb[2][32];
     int bh, oblk;
     attn_block((a.T + 127) / 128, a.nbh, bh, oblk);
@@ -303,52 +386,57 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(AttnArgs a) {
     const int key = oblk * 128 + wave * 32 + lr;
     const int kc = key < a.T ? key : a.T - 1;
     const int64_t ld = 3 * (int64_t)a.H;
-    const unsigned short* base = a.qkv + (int64_t)b * a.P * ld + h * AT_D;
-    const unsigned short* dob = a.dctx + (int64_t)b * a.P * a.H + h * AT_D;
-    bf16x8 kf[4], vf[4];
-    load_own(base + a.H, ld, kc, lh, kf);
-    load_own(base + 2 * a.H, ld, kc, lh, vf);
+    const int64_t hoff = (int64_t)b * a.P * ld + h * AT_D, coff = (int64_t)b * a.P * a.H + h * AT_D;
+    const unsigned short* base[2] = {a.qkv + hoff, PREC ? a.qkv_lo + hoff : nullptr};
+    const unsigned short* dob[2] = {a.dctx + coff, PREC ? a.dctx_lo + coff : nullptr};
+    bf16x8 kf[NPL][4], vf[NPL][4];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+        load_own(base[pl] + a.H, ld, kc, lh, kf[pl]);
+        load_own(base[pl] + 2 * a.H, ld, kc, lh, vf[pl]);
+    }
     const float c = a.scale * 1.44269504088896341f;
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[0][e] = 0.f; dk[1][e] = 0.f; dv[0][e] = 0.f; dv[1][e] = 0.f; }
     const int nt = (a.T + 31) / 32;
-    uint4 rq[1], rdo[1];
+    uint4 rq[NPL][1], rdo[NPL][1];
     float rl = INFINITY, rd = 0.f;               // lse / delta of query threadIdx.x of the tile (threads 0..31)
-    auto stats_load = [&](int qt) {
+    auto tload = [&](int qt) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            tile_load<32>(base[pl], ld, qt * 32, a.T, rq[pl]);
+            tile_load<32>(dob[pl], a.H, qt * 32, a.T, rdo[pl]);
+        }
         if (threadIdx.x < 32) {
             const int qq = qt * 32 + threadIdx.x;
             rl = qq < a.T ? a.lse[(int64_t)bh * a.Tp + qq] : INFINITY;     // exp2(-inf) = 0 for pad queries
             rd = qq < a.T ? a.delta[(int64_t)bh * a.Tp + qq] : 0.f;
         }
     };
-    auto stats_store = [&](int buf) {
+    auto tstore = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { tile_store<32>(sQb[pl][buf], rq[pl]); tile_store<32>(sdOb[pl][buf], rdo[pl]); }
         if (threadIdx.x < 32) { sLseb[buf][threadIdx.x] = rl; sDelb[buf][threadIdx.x] = rd; }
     };
-    tile_load<32>(base, ld, 0, a.T, rq);
-    tile_load<32>(dob, a.H, 0, a.T, rdo);
-    stats_load(0);
-    tile_store<32>(sQb[0], rq);
-    tile_store<32>(sdOb[0], rdo);
-    stats_store(0);
+    tload(0);
+    tstore(0);
     __syncthreads();
     for (int qt = 0; qt < nt; ++qt) {
-        const unsigned short* sQ = sQb[qt & 1];
-        const unsigned short* sdO = sdOb[qt & 1];
-        const float* sLse = sLseb[qt & 1];
-        const float* sDel = sDelb[qt & 1];
-        if (qt + 1 < nt) {
-            tile_load<32>(base, ld, (qt + 1) * 32, a.T, rq);
-            tile_load<32>(dob, a.H, (qt + 1) * 32, a.T, rdo);
-            stats_load(qt + 1);
-        }
+        const int cb = qt & 1;
+        const float* sLse = sLseb[cb];
+        const float* sDel = sDelb[cb];
+        if (qt + 1 < nt) tload(qt + 1);
         f32x16 s, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sQ, lr, lh, ks), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rm(sdO, lr, lh, ks), vf[ks], dp, 0, 0, 0);
+            const bf16x8 qh = frag_rm(sQb[0][cb], lr, lh, ks), oh = frag_rm(sdOb[0][cb], lr, lh, ks);
+            bf16x8 ql = qh, ol = oh;
+            if constexpr (PREC) { ql = frag_rm(sQb[NPL - 1][cb], lr, lh, ks); ol = frag_rm(sdOb[NPL - 1][cb], lr, lh, ks); }
+            s = mma3<PREC>(qh, ql, kf[0][ks], kf[NPL - 1][ks], s);
+            dp = mma3<PREC>(oh, ol, vf[0][ks], vf[NPL - 1][ks], dp);
         }
         float p[16], ds[16];
 #pragma unroll
@@ -359,24 +447,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv(AttnArgs a) {
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pb = pack8(p, s2), db = pack8(ds, s2);
+            bf16x8 ph, pl_, dh, dl;
+            pack8s<PREC>(p, s2, ph, pl_);
+            pack8s<PREC>(ds, s2, dh, dl);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sdO, lr, lh, dt, s2), pb, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sQ, lr, lh, dt, s2), db, dk[dt], 0, 0, 0);
+                const bf16x8 oh = frag_tr(sdOb[0][cb], lr, lh, dt, s2), qh = frag_tr(sQb[0][cb], lr, lh, dt, s2);
+                bf16x8 ol = oh, ql = qh;
+                if constexpr (PREC) { ol = frag_tr(sdOb[NPL - 1][cb], lr, lh, dt, s2); ql = frag_tr(sQb[NPL - 1][cb], lr, lh, dt, s2); }
+                dv[dt] = mma3<PREC>(oh, ol, ph, pl_, dv[dt]);
+                dk[dt] = mma3<PREC>(qh, ql, dh, dl, dk[dt]);
             }
         }
-        if (qt + 1 < nt) {
-            tile_store<32>(sQb[(qt + 1) & 1], rq);
-            tile_store<32>(sdOb[(qt + 1) & 1], rdo);
-            stats_store((qt + 1) & 1);
-        }
+        if (qt + 1 < nt) tstore((qt + 1) & 1);
         __syncthreads();
     }
     if (key < a.T) {
-        unsigned short* o = a.dqkv + (int64_t)b * a.P * ld + h * AT_D;
-        store_own(o + a.H, ld, key, lh, dk, a.scale);
-        store_own(o + 2 * a.H, ld, key, lh, dv, 1.f);
+        store_own_s<PREC>(a.dqkv + hoff + a.H, PREC ? a.dqkv_lo + hoff + a.H : nullptr, ld, key, lh, dk, a.scale);
+        store_own_s<PREC>(a.dqkv + hoff + 2 * a.H, PREC ? a.dqkv_lo + hoff + 2 * a.H : nullptr, ld, key, lh, dv, 1.f);
     }
 }
 
@@ -389,7 +477,8 @@ static paa_status attn_check(const AttnArgs& a, int B, int head_dim) {
 paa_status attn_fwd(const AttnArgs& a, int B, int head_dim, hipStream_t st) {
     PAA_TRY(attn_check(a, B, head_dim));
     AttnArgs f = a; f.nbh = B * a.nh;
-    hipLaunchKernelGGL(k_attn_fwd, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
+    if (a.qkv_lo) hipLaunchKernelGGL(k_attn_fwd<1>, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
+    else hipLaunchKernelGGL(k_attn_fwd<0>, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
@@ -397,9 +486,11 @@ paa_status attn_fwd(const AttnArgs& a, int B, int head_dim, hipStream_t st) {
 paa_status attn_bwd(const AttnArgs& a, int B, int head_dim, hipStream_t st) {
     PAA_TRY(attn_check(a, B, head_dim));
     AttnArgs f = a; f.nbh = B * a.nh;
-    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
+    if (a.qkv_lo) hipLaunchKernelGGL(k_attn_bwd_dq<1>, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
+    else hipLaunchKernelGGL(k_attn_bwd_dq<0>, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
     PAA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
+    if (a.qkv_lo) hipLaunchKernelGGL(k_attn_bwd_dkv<1>, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
+    else hipLaunchKernelGGL(k_attn_bwd_dkv<0>, dim3(cdiv(a.T, 128) * B * a.nh), dim3(256), 0, st, f);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
@@ -420,5 +511,27 @@ extern "C" paa_status paa_attn_bwd(const void* qkv, const void* ctx, const float
     a.qkv = (const unsigned short*)qkv; a.ctx = (unsigned short*)ctx; a.lse = (float*)lse;
     a.dctx = (const unsigned short*)dctx; a.delta = delta; a.dqkv = (unsigned short*)dqkv;
     a.T = T; a.P = P; a.Tp = Tp; a.H = H; a.nh = nh; a.scale = 1.0f / sqrtf((float)(H / nh));
+    return paa::attn_bwd(a, B, H / nh, (hipStream_t)stream);
+}
+// Split-bf16 (hi + lo planes) forms of the two test entries.
+extern "C" paa_status paa_attn_fwd_split(const void* qkv_hi, const void* qkv_lo, void* ctx_hi, void* ctx_lo, float* lse, int B,
+                                         int T, int P, int Tp, int H, int nh, void* stream) {
+    paa::AttnArgs a{};
+    a.qkv = (const unsigned short*)qkv_hi; a.qkv_lo = (const unsigned short*)qkv_lo;
+    a.ctx = (unsigned short*)ctx_hi; a.ctx_lo = (unsigned short*)ctx_lo; a.lse = lse;
+    a.T = T; a.P = P; a.Tp = Tp; a.H = H; a.nh = nh; a.scale = 1.0f / sqrtf((float)(H / nh));
+    if (!qkv_lo || !ctx_lo) { paa::set_error("paa_attn_fwd_split: lo planes required"); return PAA_ERR_ARG; }
+    return paa::attn_fwd(a, B, H / nh, (hipStream_t)stream);
+}
+extern "C" paa_status paa_attn_bwd_split(const void* qkv_hi, const void* qkv_lo, const void* ctx_hi, const void* ctx_lo,
+                                         const float* lse, const void* dctx_hi, const void* dctx_lo, float* delta,
+                                         void* dqkv_hi, void* dqkv_lo, int B, int T, int P, int Tp, int H, int nh, void* stream) {
+    paa::AttnArgs a{};
+    a.qkv = (const unsigned short*)qkv_hi; a.qkv_lo = (const unsigned short*)qkv_lo;
+    a.ctx = (unsigned short*)ctx_hi; a.ctx_lo = (unsigned short*)ctx_lo; a.lse = (float*)lse;
+    a.dctx = (const unsigned short*)dctx_hi; a.dctx_lo = (const unsigned short*)dctx_lo; a.delta = delta;
+    a.dqkv = (unsigned short*)dqkv_hi; a.dqkv_lo = (unsigned short*)dqkv_lo;
+    a.T = T; a.P = P; a.Tp = Tp; a.H = H; a.nh = nh; a.scale = 1.0f / sqrtf((float)(H / nh));
+    if (!qkv_lo || !ctx_lo || !dctx_lo || !dqkv_lo) { paa::set_error("paa_attn_bwd_split: lo planes required"); return PAA_ERR_ARG; }
     return paa::attn_bwd(a, B, H / nh, (hipStream_t)stream);
 }

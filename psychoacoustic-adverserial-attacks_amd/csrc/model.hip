@@ -85,7 +85,7 @@ struct paa_model {
     paa_arch a;
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
-    bool fused;                      // flash-style attention kernels (bf16 mode, head_dim 64); else materialised scores
+    bool fused;                      // flash-style attention kernels (head_dim 64); else materialised scores
     bool pre16;                      // bf16 mode: what a GELU keeps for its backward pass (L{l}.fpre, and conv{i}.pre, i < last,
                                      // of the group-norm extractor) is stored as bf16 AND as the derivative gelu'(v) itself
                                      // (paa_gemm_desc.aux_bf16 / aux_gate): it only ever multiplies a gradient
@@ -148,7 +148,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     if (max_batch < 1 || length < 1) PAA_FAIL(PAA_ERR_SIZE, "max_batch/length");
     paa_model* m = new paa_model();
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
-    m->fused = (m->prec == 0) && (a.hidden / a.heads == 64);
+    m->fused = a.hidden / a.heads == 64;      // flash-style kernels; split-bf16 (hi + lo planes) in fp32-parity mode
     m->pre16 = m->prec == 0;
     for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
 
@@ -398,7 +398,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         if (m->fused) {
             PAA_TRY(linear(m, attn_in, e.wqkv, e.bqkv, nullptr, e.qkvH, M, 3 * H, H, st));
             AttnArgs aa{};
-            aa.qkv = e.qkvH.hi; aa.ctx = e.ctxH.hi; aa.lse = e.lse;
+            aa.qkv = e.qkvH.hi; aa.ctx = e.ctxH.hi; aa.lse = e.lse; aa.qkv_lo = e.qkvH.lo; aa.ctx_lo = e.ctxH.lo;
             aa.T = T; aa.P = P; aa.Tp = Tp; aa.H = H; aa.nh = nh; aa.scale = scale;
             PAA_TRY(attn_fwd(aa, B, hd, st));
             ctxH = ro(e.ctxH);
@@ -470,6 +470,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             PAA_TRY(linear(m, ro(dx2H), e.wo_t, nullptr, nullptr, m->dctxH, M, H, H, st));
             AttnArgs aa{};
             aa.qkv = e.qkvH.hi; aa.ctx = e.ctxH.hi; aa.lse = e.lse; aa.dctx = m->dctxH.hi; aa.delta = m->delta; aa.dqkv = m->dqkvH.hi;
+            aa.qkv_lo = e.qkvH.lo; aa.ctx_lo = e.ctxH.lo; aa.dctx_lo = m->dctxH.lo; aa.dqkv_lo = m->dqkvH.lo;
             aa.T = T; aa.P = P; aa.Tp = Tp; aa.H = H; aa.nh = nh; aa.scale = scale;
             PAA_TRY(attn_bwd(aa, B, hd, st));
         } else {

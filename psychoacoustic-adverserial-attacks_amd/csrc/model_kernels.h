@@ -66,6 +66,10 @@ struct AttnArgs {
     const unsigned short* dctx;     // (M, H)   dO
     float* delta;                   // (B*nh, Tp) rowsum(dO * O)
     unsigned short* dqkv;           // (M, 3H): dQ | dK | dV
+    const unsigned short* qkv_lo;   // lo planes of the same tensors (split-bf16 mode; all null in bf16 mode)
+    unsigned short* ctx_lo;
+    const unsigned short* dctx_lo;
+    unsigned short* dqkv_lo;
     int T, P, Tp, H, nh;
     int nbh;                        // B * nh (set by the launcher)
     float scale;                    // head_dim^-0.5

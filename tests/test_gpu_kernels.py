@@ -320,3 +320,43 @@ def test_fused_attention(T, B, nh):
     print(f"attention T={T}: O {e_o:.2e} dQ {e_q:.2e} dK {e_k:.2e} dV {e_v:.2e}")
     assert e_o < 1e-2 and e_q < 2e-2 and e_k < 2e-2 and e_v < 2e-2     # bf16 P / dS and bf16 outputs
     assert float(ctx[:, T:].abs().max()) == 0 and float(dqkv[:, T:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("T,B,nh", [(499, 2, 3), (70, 1, 2), (131, 2, 2)])
+def test_fused_attention_split(T, B, nh):
+    """The same kernels with hi + lo planes (split-bf16, fp32-parity mode) vs torch float64 on the f32 inputs."""
+    from paa_amd.model import bf16_to_f32, split_bf16
+    torch.manual_seed(4)
+    hd, P, Tp = 64, T + 1, (T + 31) // 32 * 32
+    H = nh * hd
+    qkv = (torch.randn(B, P, 3 * H) * 1.5).numpy()
+    do = torch.randn(B, P, H).numpy()
+    qh, ql = split_bf16(qkv)
+    dh, dl = split_bf16(do)
+    qv = bf16_to_f32(qh).astype(np.float64) + bf16_to_f32(ql)
+    dv = bf16_to_f32(dh).astype(np.float64) + bf16_to_f32(dl)
+    qr = torch.from_numpy(qv).requires_grad_(True)
+    q, k, v = (qr[:, :T, i * H:(i + 1) * H].reshape(B, T, nh, hd).transpose(1, 2) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1)
+    o = (att @ v).transpose(1, 2).reshape(B, T, H)
+    o.backward(torch.from_numpy(dv)[:, :T])
+    dev16 = lambda x: torch.from_numpy(x.view(np.int16)).cuda()
+    d_qh, d_ql, d_dh, d_dl = dev16(qh), dev16(ql), dev16(dh), dev16(dl)
+    z = lambda *shape: torch.zeros(*shape, dtype=torch.int16, device="cuda")
+    ch, cl, gh, gl = z(B, P, H), z(B, P, H), z(B, P, 3 * H), z(B, P, 3 * H)
+    lse = torch.zeros(B * nh, Tp, device="cuda")
+    delta = torch.zeros(B * nh, Tp, device="cuda")
+    L = _lib.lib()
+    _lib.check(L.paa_attn_fwd_split(_lib.ptr(d_qh), _lib.ptr(d_ql), _lib.ptr(ch), _lib.ptr(cl), _lib.ptr(lse), B, T, P, Tp, H, nh,
+                                    _lib.stream_ptr()))
+    _lib.check(L.paa_attn_bwd_split(_lib.ptr(d_qh), _lib.ptr(d_ql), _lib.ptr(ch), _lib.ptr(cl), _lib.ptr(lse), _lib.ptr(d_dh),
+                                    _lib.ptr(d_dl), _lib.ptr(delta), _lib.ptr(gh), _lib.ptr(gl), B, T, P, Tp, H, nh, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    planes = lambda hi, lo: bf16_to_f32(hi.cpu().numpy().view(np.uint16)).astype(np.float64) + bf16_to_f32(lo.cpu().numpy().view(np.uint16))
+    og, dg = planes(ch, cl)[:, :T], planes(gh, gl)[:, :T]
+    e_o = rel_err(og, o.detach().numpy())
+    gref = qr.grad.numpy()[:, :T]
+    e_q, e_k, e_v = (rel_err(dg[..., i * H:(i + 1) * H], gref[..., i * H:(i + 1) * H]) for i in range(3))
+    print(f"split attention T={T}: O {e_o:.2e} dQ {e_q:.2e} dK {e_k:.2e} dV {e_v:.2e}")
+    assert e_o < 5e-5 and e_q < 1e-4 and e_k < 1e-4 and e_v < 1e-4
+    assert float(ch[:, T:].abs().max()) == 0 and float(gh[:, T:].abs().max()) == 0
