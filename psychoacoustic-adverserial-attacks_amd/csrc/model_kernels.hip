@@ -19,22 +19,33 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * cols;
+    // the first 1024 columns of the row are read ONCE and kept in registers (4 float4 per lane); wider rows re-read the rest
+    float4 xr4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = lane * 4 + 256 * u;
+        xr4[u] = c < cols ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float s = 0.f;
-    for (int c = lane * 4; c < cols; c += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += (xr4[u].x + xr4[u].y) + (xr4[u].z + xr4[u].w);       // columns past the row are zeros
+    for (int c = 1024 + lane * 4; c < cols; c += 256) {
         const float4 v = *reinterpret_cast<const float4*>(xr + c);
         s += (v.x + v.y) + (v.z + v.w);
     }
     const float mean = wave_sum(s) / (float)cols;
     float q = 0.f;
-    for (int c = lane * 4; c < cols; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    auto sq = [&](const float4& v) {
         const float a = v.x - mean, bb = v.y - mean, cc = v.z - mean, dd = v.w - mean;
         q += (a * a + bb * bb) + (cc * cc + dd * dd);
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane * 4 + 256 * u < cols) sq(xr4[u]);
+    for (int c = 1024 + lane * 4; c < cols; c += 256) sq(*reinterpret_cast<const float4*>(xr + c));
     const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
     if (lane == 0 && stats) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
-    for (int c = lane * 4; c < cols; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    auto emit = [&](int c, const float4& v) {
         const float4 gg = *reinterpret_cast<const float4*>(g + c);
         const float4 bv = *reinterpret_cast<const float4*>(b + c);
         float o[4];
@@ -52,7 +63,11 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
             store_bf16x4(actb, i0, ga);
             if (yact) *reinterpret_cast<float4*>(yact + i0) = make_float4(ga[0], ga[1], ga[2], ga[3]);
         }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane * 4 + 256 * u < cols) emit(lane * 4 + 256 * u, xr4[u]);
+    for (int c = 1024 + lane * 4; c < cols; c += 256) emit(c, *reinterpret_cast<const float4*>(xr + c));
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ add];  if gelu_pre: dy *= gelu'(gelu_pre) first
@@ -65,45 +80,63 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     if (row >= rows) return;
     const size_t o = (size_t)row * cols;
     const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    // dy (with the optional gelu' factor applied) and x of the first 1024 columns stay in registers between the two passes
+    float dr[4][4], xh[4][4];
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane * 4; c < cols; c += 256) {
+    auto chunk = [&](int c, float (&d)[4], float (&xv)[4]) {          // loads one chunk: d = dy [* gelu'], xv = xhat
         const float4 d4 = *reinterpret_cast<const float4*>(dy + o + c);
         const float4 x4 = *reinterpret_cast<const float4*>(x + o + c);
-        const float4 g4 = *reinterpret_cast<const float4*>(g + c);
-        float d[4] = {d4.x, d4.y, d4.z, d4.w};
-        const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
         if (gelu_pre) {
             const float4 p4 = *reinterpret_cast<const float4*>(gelu_pre + o + c);
             d[0] *= gelu_grad_f(p4.x); d[1] *= gelu_grad_f(p4.y); d[2] *= gelu_grad_f(p4.z); d[3] *= gelu_grad_f(p4.w);
         }
+        xv[0] = (x4.x - mean) * rstd; xv[1] = (x4.y - mean) * rstd; xv[2] = (x4.z - mean) * rstd; xv[3] = (x4.w - mean) * rstd;
+    };
+    auto sums = [&](int c, const float (&d)[4], const float (&xv)[4]) {
+        const float4 g4 = *reinterpret_cast<const float4*>(g + c);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float gd = gv[j] * d[j];
             s1 += gd;
-            s2 += gd * ((xv[j] - mean) * rstd);
+            s2 += gd * xv[j];
         }
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = lane * 4 + 256 * u;
+        if (c < cols) { chunk(c, dr[u], xh[u]); sums(c, dr[u], xh[u]); }
+    }
+    for (int c = 1024 + lane * 4; c < cols; c += 256) {
+        float d[4], xv[4];
+        chunk(c, d, xv);
+        sums(c, d, xv);
     }
     s1 = wave_sum(s1) / (float)cols;
     s2 = wave_sum(s2) / (float)cols;
-    for (int c = lane * 4; c < cols; c += 256) {
-        const float4 d4 = *reinterpret_cast<const float4*>(dy + o + c);
-        const float4 x4 = *reinterpret_cast<const float4*>(x + o + c);
+    auto emit = [&](int c, const float (&d)[4], const float (&xv)[4]) {
         const float4 g4 = *reinterpret_cast<const float4*>(g + c);
-        float d[4] = {d4.x, d4.y, d4.z, d4.w};
-        const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
-        if (gelu_pre) {
-            const float4 p4 = *reinterpret_cast<const float4*>(gelu_pre + o + c);
-            d[0] *= gelu_grad_f(p4.x); d[1] *= gelu_grad_f(p4.y); d[2] *= gelu_grad_f(p4.z); d[3] *= gelu_grad_f(p4.w);
-        }
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rstd * (gv[j] * d[j] - s1 - ((xv[j] - mean) * rstd) * s2);
+        for (int j = 0; j < 4; ++j) v[j] = rstd * (gv[j] * d[j] - s1 - xv[j] * s2);
         if (add) {
             const float4 a4 = *reinterpret_cast<const float4*>(add + o + c);
             v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
         }
         if (dx) *reinterpret_cast<float4*>(dx + o + c) = make_float4(v[0], v[1], v[2], v[3]);
         store_bf16x4(dxb, o + c, v);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = lane * 4 + 256 * u;
+        if (c < cols) emit(c, dr[u], xh[u]);
+    }
+    for (int c = 1024 + lane * 4; c < cols; c += 256) {
+        float d[4], xv[4];
+        chunk(c, d, xv);
+        emit(c, d, xv);
     }
 }
 
