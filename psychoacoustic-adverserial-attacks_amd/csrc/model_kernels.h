@@ -47,7 +47,21 @@ struct Conv0Args {
     float* kc;               //   (B, 16)    sum_c W1_b[c][j] * (s2_bc * rstd_bc * mean_bc - s1_bc)
     float* part;             // scratch partials
 };
+// Input sample i of clip b: clamp(clean[b][i] + p[i], -1, 1) (train.py:136) — or clean + p unclamped
+// (evaluation.py:16) — or clean alone when p is null.  Never materialised.
+__device__ __forceinline__ float in_sample(const Conv0Args& a, int b, int i) {
+    float v = a.clean[(size_t)b * a.L + i];
+    if (a.p) {
+        v += a.p[i];
+        if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+    }
+    return v;
+}
 paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st);
+// conv0_dgrad.hip: single-pass G1 + GroupNorm backward sums (bf16 mode)
+bool conv0_dgrad_supported(const Conv0Args& a);
+int64_t conv0_dgrad_part_floats(int B, int T, int C);
+paa_status conv0_dgrad_fused(const Conv0Args& a, float* part, hipStream_t st);
 paa_status conv0_ln_forward(const Conv0Args& a, hipStream_t st);
 paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, float* part, float* grad, hipStream_t st);
 int conv0_chunks(int T);

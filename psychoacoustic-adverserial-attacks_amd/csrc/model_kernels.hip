@@ -206,16 +206,7 @@ paa_status softmax_bwd(float* dp, const float* p, int n_mat, int rows_per_mat, i
 }
 
 // ============================================================================ conv0 (C_in=1) ===
-// Input sample i of clip b: clamp(clean[b][i] + p[i], -1, 1) (train.py:136) — or clean + p unclamped
-// (evaluation.py:16) — or clean alone when p is null.  Never materialised.
-__device__ __forceinline__ float in_sample(const Conv0Args& a, int b, int i) {
-    float v = a.clean[(size_t)b * a.L + i];
-    if (a.p) {
-        v += a.p[i];
-        if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
-    }
-    return v;
-}
+// in_sample(a, b, i): input sample i of clip b (model_kernels.h)
 
 constexpr int C0_TCH = 128;  // frames per workgroup in the channel-per-thread kernels
 
@@ -576,8 +567,9 @@ __global__ void k_input_grad(Conv0Args a, float* __restrict__ grad) {
 //            = (dy[b,t,:] . W1_b[:,j]) + kc_b[j] - sum_j' Mx_b[j,j'] x[b, t*stride + j']
 // with W1_b[c,j] = w[c,j] gamma_c rstd_bc.  The first term is a GEMM over the bf16 planes of dy (per-clip B
 // operand); this kernel builds W1_b (bf16 planes, [16][C] per clip), Mx_b and kc_b.  One workgroup per clip.
-__global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a) {
-    __shared__ double red[256 / 64];
+// mode 0: everything; 1: W1_b only (needs the forward statistics alone); 2: Mx_b and kc_b only (needs gn_bsums).
+__global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a, int mode) {
+    __shared__ double red[256 / 64][110];
     const int b = blockIdx.x;
     float acc[10][11];
 #pragma unroll
@@ -586,7 +578,8 @@ __global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a) {
         for (int q = 0; q < 11; ++q) acc[j][q] = 0.f;
     for (int c = threadIdx.x; c < a.C; c += 256) {
         const float mean = a.gn_stats[((size_t)b * a.C + c) * 2], rstd = a.gn_stats[((size_t)b * a.C + c) * 2 + 1];
-        const float s1 = a.gn_bsums[((size_t)b * a.C + c) * 2], s2 = a.gn_bsums[((size_t)b * a.C + c) * 2 + 1];
+        float s1 = 0.f, s2 = 0.f;
+        if (mode != 1) { s1 = a.gn_bsums[((size_t)b * a.C + c) * 2]; s2 = a.gn_bsums[((size_t)b * a.C + c) * 2 + 1]; }
         const float gr = a.gamma[c] * rstd;
         float w[10], w1[10];
 #pragma unroll
@@ -595,12 +588,13 @@ __global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a) {
             const float v = w[j] * gr;
             const size_t o = ((size_t)b * 16 + j) * a.C + c;
             const unsigned short h = bf16_bits(v);
-            a.w1b.hi[o] = h;
+            if (mode != 2) a.w1b.hi[o] = h;
             float vr = bf16_to_f32(h);
-            if (a.w1b.lo) { const unsigned short l = bf16_bits(v - vr); a.w1b.lo[o] = l; vr += bf16_to_f32(l); }
+            if (a.w1b.lo) { const unsigned short l = bf16_bits(v - vr); if (mode != 2) a.w1b.lo[o] = l; vr += bf16_to_f32(l); }
             w1[j] = vr;                                   // the value the GEMM will actually multiply with
         }
-        for (int j = 10; j < 16; ++j) { const size_t o = ((size_t)b * 16 + j) * a.C + c; a.w1b.hi[o] = 0; if (a.w1b.lo) a.w1b.lo[o] = 0; }
+        if (mode != 2)
+            for (int j = 10; j < 16; ++j) { const size_t o = ((size_t)b * 16 + j) * a.C + c; a.w1b.hi[o] = 0; if (a.w1b.lo) a.w1b.lo[o] = 0; }
         const float sr = s2 * rstd;
 #pragma unroll
         for (int j = 0; j < 10; ++j) {
@@ -609,16 +603,25 @@ __global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a) {
             acc[j][10] += w1[j] * (sr * mean - s1);
         }
     }
+    if (mode == 1) return;
+    // 110 sums over the block: wave sums in f64, one LDS exchange, fixed order over the four waves
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 10; ++j)
 #pragma unroll
         for (int q = 0; q < 11; ++q) {
-            const double t = block_sum<double, 256>((double)acc[j][q], red);
-            if (threadIdx.x == 0 && j < a.k) {
-                if (q < 10) { if (q < a.k) a.Mx[((size_t)b * a.k + j) * a.k + q] = (float)t; }
-                else a.kc[(size_t)b * 16 + j] = (float)t;
-            }
+            const double t = wave_sum((double)acc[j][q]);
+            if ((threadIdx.x & 63) == 0) red[wv][j * 11 + q] = t;
         }
+    __syncthreads();
+    if (threadIdx.x < 110) {
+        const int j = threadIdx.x / 11, q = threadIdx.x - 11 * j;
+        const double t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (j < a.k) {
+            if (q < 10) { if (q < a.k) a.Mx[((size_t)b * a.k + j) * a.k + q] = (float)t; }
+            else a.kc[(size_t)b * 16 + j] = (float)t;
+        }
+    }
 }
 
 // grad[l] = sum_b mask_b[l] * sum_{(t, j): t*stride + j = l} G[b][t][j], G from the GEMM result G1 (see above).
@@ -697,6 +700,17 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
         PAA_LAUNCH_CHECK();
         return PAA_OK;
     }
+    if (!precision && conv0_dgrad_supported(a)) {
+        // bf16 mode: W1_b first (forward statistics only), then ONE pass over dy for G1 and the GroupNorm sums
+        hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a, 1);
+        PAA_LAUNCH_CHECK();
+        PAA_TRY(conv0_dgrad_fused(a, part, st));
+        hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a, 2);
+        PAA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_input_grad_gn, dim3(cdiv(a.L, 256)), dim3(256), 0, st, a, grad);
+        PAA_LAUNCH_CHECK();
+        return PAA_OK;
+    }
     const int nchunk = cdiv(a.T, C0_TCH);
     const size_t lds = sizeof(float) * ((C0_TCH - 1) * a.stride + 10 + 8);
     Conv0Args b = a;
@@ -706,7 +720,7 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
     hipLaunchKernelGGL(k_conv0_gn_finalize, dim3(cdiv(a.B * a.C, 64)), dim3(256), 0, st, (const float*)part,
                        (float*)a.gn_bsums, a.B, a.C, nchunk, a.T);
     PAA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a, 0);
     PAA_LAUNCH_CHECK();
     paa_gemm_desc d{};                    // G1[b] (P x 16) = dy[b] (P x C) . W1_b^T
     d.operand_bf16 = 1; d.precision = precision;
@@ -1179,7 +1193,8 @@ static paa_status launch_ctc_ws(const float* logits, const int32_t* labels, int 
 int conv0_chunks(int T) { return cdiv(T, C0_TCH); }
 // floats of the conv0 partial-sum workspace: per-chunk channel partials (backward) or Gram partials in f64 (forward)
 int64_t conv0_part_floats(int B, int T, int C) {
-    return std::max((int64_t)B * cdiv(T, C0_TCH) * C * 2, (int64_t)B * cdiv(T, C0_GCH) * C0_GQ * 2) + 64;
+    return std::max(std::max((int64_t)B * cdiv(T, C0_TCH) * C * 2, (int64_t)B * cdiv(T, C0_GCH) * C0_GQ * 2),
+                    conv0_dgrad_part_floats(B, T, C)) + 64;
 }
 
 // states per lane of the wave-synchronous kernel for a label capacity (0: use the log-domain kernel)
