@@ -625,12 +625,17 @@ __global__ __launch_bounds__(256) void k_conv0_bwd_prep(Conv0Args a, int mode) {
 }
 
 // grad[l] = sum_b mask_b[l] * sum_{(t, j): t*stride + j = l} G[b][t][j], G from the GEMM result G1 (see above).
-// A workgroup owns 256 consecutive samples and walks the clips in order (fixed summation order); per clip the input
-// window it needs, Mx_b and kc_b are staged in LDS once instead of being recomputed / re-read per (frame, tap).
+// A workgroup owns 64 consecutive samples; its four waves walk the clips b = wave, wave + 4, ... (each step is two
+// dependent global round trips — input window / Mx / kc into LDS, then G1 — so four clips in flight per workgroup and
+// four times as many workgroups hide what a single walk over all clips exposed).  Per clip the input window, Mx_b and
+// kc_b are staged in LDS once instead of being recomputed / re-read per (frame, tap).  Fixed summation order.
+constexpr int IG_S = 64;
 __global__ __launch_bounds__(256) void k_input_grad_gn(Conv0Args a, float* __restrict__ grad) {
-    __shared__ float xs[256 + 2 * 10 + 4];
-    __shared__ float smx[10 * 10], skc[16];
-    const int l0 = blockIdx.x * 256, l = l0 + threadIdx.x;
+    __shared__ float xs[4][IG_S + 2 * 10 + 4];
+    __shared__ float smx[4][10 * 10], skc[4][16];
+    __shared__ float part[4][IG_S];
+    const int ls = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int l0 = blockIdx.x * IG_S, l = l0 + ls;
     const int lc = l < a.L ? l : a.L - 1;
     int t_hi = lc / a.stride;
     int t_lo = (lc - a.k + 1 + a.stride - 1);
@@ -638,21 +643,26 @@ __global__ __launch_bounds__(256) void k_input_grad_gn(Conv0Args a, float* __res
     if (t_hi > a.T - 1) t_hi = a.T - 1;
     const int w0 = l0 - a.k;                                  // first sample of the staged window
     float total = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-        __syncthreads();                                      // everyone is done with the previous clip's tiles
-        for (int i = threadIdx.x; i < 256 + 2 * a.k; i += 256) {
-            const int sidx = w0 + i;
-            xs[i] = (sidx >= 0 && sidx < a.L) ? in_sample(a, b, sidx) : 0.f;
+    for (int b0 = 0; b0 < a.B; b0 += 4) {
+        const int b = b0 + cg;
+        const bool on = b < a.B;
+        __syncthreads();                                      // everyone is done with the previous clips' tiles
+        if (on) {
+            for (int i = ls; i < IG_S + 2 * a.k; i += 64) {
+                const int sidx = w0 + i;
+                xs[cg][i] = (sidx >= 0 && sidx < a.L) ? in_sample(a, b, sidx) : 0.f;
+            }
+            for (int i = ls; i < a.k * a.k; i += 64) smx[cg][i] = a.Mx[(size_t)b * a.k * a.k + i];
+            if (ls < 16) skc[cg][ls] = a.kc[(size_t)b * 16 + ls];
         }
-        if (threadIdx.x < a.k * a.k) smx[threadIdx.x] = a.Mx[(size_t)b * a.k * a.k + threadIdx.x];
-        if (threadIdx.x < 16) skc[threadIdx.x] = a.kc[(size_t)b * 16 + threadIdx.x];
         __syncthreads();
+        if (!on) continue;
         float gsum = 0.f;
         for (int t = t_lo; t <= t_hi; ++t) {
             const int j = lc - t * a.stride;
-            float g = a.G1[((size_t)b * a.P + t) * 16 + j] + skc[j];
-            const float* mx = smx + j * a.k;
-            const float* xw = xs + (t * a.stride - w0);
+            float g = a.G1[((size_t)b * a.P + t) * 16 + j] + skc[cg][j];
+            const float* mx = smx[cg] + j * a.k;
+            const float* xw = xs[cg] + (t * a.stride - w0);
             for (int q = 0; q < a.k; ++q) g -= mx[q] * xw[q];
             gsum += g;
         }
@@ -662,7 +672,9 @@ __global__ __launch_bounds__(256) void k_input_grad_gn(Conv0Args a, float* __res
         }
         total += gsum;
     }
-    if (l < a.L) grad[l] = total;
+    part[cg][ls] = total;
+    __syncthreads();
+    if (cg == 0 && l < a.L) grad[l] = (part[0][ls] + part[1][ls]) + (part[2][ls] + part[3][ls]);
 }
 
 paa_status conv0_gn_forward(const Conv0Args& a, float* part, hipStream_t st) {
@@ -707,7 +719,7 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
         PAA_TRY(conv0_dgrad_fused(a, part, st));
         hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a, 2);
         PAA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_input_grad_gn, dim3(cdiv(a.L, 256)), dim3(256), 0, st, a, grad);
+        hipLaunchKernelGGL(k_input_grad_gn, dim3(cdiv(a.L, IG_S)), dim3(256), 0, st, a, grad);
         PAA_LAUNCH_CHECK();
         return PAA_OK;
     }
@@ -731,7 +743,7 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
     d.a_kcontig = 1; d.b_kcontig = 1; d.alpha = 1.f;
     d.batch = a.B; d.batch2 = 1; d.a_s1 = (int64_t)a.P * a.C; d.b_s1 = (int64_t)16 * a.C; d.c_s1 = (int64_t)a.P * 16;
     PAA_TRY(gemm(d, st));
-    hipLaunchKernelGGL(k_input_grad_gn, dim3(cdiv(a.L, 256)), dim3(256), 0, st, a, grad);
+    hipLaunchKernelGGL(k_input_grad_gn, dim3(cdiv(a.L, IG_S)), dim3(256), 0, st, a, grad);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
