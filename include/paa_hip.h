@@ -151,6 +151,10 @@ paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
  * of the grouped positional convolution) and resets. */
 paa_status paa_prof_enable(int max_launches);
 paa_status paa_prof_read(double* out192);
+/* paa_prof_pause(1) stops recording without releasing the events, paa_prof_pause(0) resumes: bench.py creates the
+ * events before its timed region and records on the LAST timed step only (the first timing event recorded on a HIP
+ * stream switches its queue to profiled dispatch for good, which costs ~4 % on every later launch). */
+paa_status paa_prof_pause(int paused);
 /* Fused attention (head_dim 64, bf16 planes as uint16): qkv (B*P, 3H) = Q|K|V, ctx/dctx (B*P, H), lse/delta (B*nh, Tp) */
 paa_status paa_attn_fwd(const void* qkv, void* ctx, float* lse, int B, int T, int P, int Tp, int H, int nh, void* stream);
 paa_status paa_attn_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, float* delta, void* dqkv,

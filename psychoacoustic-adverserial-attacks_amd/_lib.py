@@ -81,6 +81,7 @@ _SIGS = {
     "paa_gemm": (C.c_int, [C.POINTER(PaaGemmDesc), C.c_void_p]),
     "paa_prof_enable": (C.c_int, [C.c_int]),
     "paa_prof_read": (C.c_int, [C.c_void_p]),
+    "paa_prof_pause": (C.c_int, [C.c_int]),
     "paa_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "paa_attn_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]),
     "paa_attn_fwd_split": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),

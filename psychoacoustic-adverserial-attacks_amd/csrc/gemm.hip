@@ -985,6 +985,11 @@ extern "C" paa_status paa_prof_read(double* out96) {
     return PAA_OK;
 }
 
+extern "C" paa_status paa_prof_pause(int paused) {
+    paa::g_prof.on = !paused && paa::g_prof.cap > 0;
+    return PAA_OK;
+}
+
 extern "C" paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream) {
     if (!d) { paa::set_error("paa_gemm: null descriptor"); return PAA_ERR_ARG; }
     return paa::gemm(*d, (hipStream_t)stream);
