@@ -935,6 +935,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             if (seg) { if (d.precision) launch_bf<128, 64, 1, 2, false, true>(g, st); else launch_bf<128, 64, 0, 2, false, true>(g, st); }
             else { if (d.precision) launch_bf<128, 64, 1, 2, false, false>(g, st); else launch_bf<128, 64, 0, 2, false, false>(g, st); }
         }
+        else if (seg && vec && !d.precision) launch_bf<128, 128, 0, 2, true, true>(g, st);      // lm-head dgrad (K = vocab)
         else if (seg) { if (d.precision) launch_bf<128, 128, 1, 2, false, true>(g, st); else launch_bf<128, 128, 0, 2, false, true>(g, st); }
         else if (tall) {
             if (d.precision) launch_bf<256, 128, 1, 4, true, false>(g, st);
