@@ -101,9 +101,11 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
 
+    import contextlib
     import __graft_entry__
     if rank == 0:
-        __graft_entry__.build()
+        with contextlib.redirect_stdout(sys.stderr):      # stdout carries the one JSON line and nothing else
+            __graft_entry__.build()
     if world > 1:
         torch.distributed.barrier()
     from paa_amd import _lib, arch as A, synth
