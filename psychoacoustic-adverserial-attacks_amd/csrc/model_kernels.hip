@@ -5,6 +5,8 @@
 // Third-party algorithm restated (HuggingFace transformers modeling_wav2vec2.py, torch ATen):
 //   Wav2Vec2GroupNormConvLayer / Wav2Vec2LayerNormConvLayer (:275-323), nn.LayerNorm, softmax,
 //   F.ctc_loss(reduction='sum', zero_infinity=False) and its backward.
+#include <cstdlib>
+
 #include "model_kernels.h"
 
 namespace paa {
@@ -712,7 +714,9 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
         PAA_LAUNCH_CHECK();
         return PAA_OK;
     }
-    if (!precision && conv0_dgrad_supported(a)) {
+    // PAA_CONV0_TWO_PASS=1 (tests): keep the statistics pass + GEMM pass also in bf16 mode, to compare the two paths
+    const char* two_pass = getenv("PAA_CONV0_TWO_PASS");
+    if (!precision && conv0_dgrad_supported(a) && !(two_pass && two_pass[0] == '1')) {
         // bf16 mode: W1_b first (forward statistics only), then ONE pass over dy for G1 and the GroupNorm sums
         hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a, 1);
         PAA_LAUNCH_CHECK();
