@@ -718,10 +718,13 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
 // the general loader every K tile re-reads its shifted A rows from L2 — ~100 times per output tile; here the
 // 128 + taps - 1 input rows a 128-row output tile touches are loaded ONCE into an LDS slab and every tap reads its
 // shifted 32-row window of it (row stride KS + 8 bf16: conflict-free ds_read_b128).  The weights stream through a
-// register-prefetched LDS stage of TB = 4 taps.  4 waves, 32 output rows x 64 (N padded) columns each.
-template <int PREC, int KS>
+// register-prefetched LDS stage of TB = 4 taps.  4 waves, 32 MI output rows x 64 (N padded) columns each: with MI = 2
+// a wave issues 4 MFMAs per 4 fragment reads (MI = 1: 2 per 3) and the slab's halo of taps - 1 rows is amortised over
+// 256 output rows instead of 128 (+11 % on the kernel; requesting the weight stages two ahead through a second
+// register set changed nothing on top of that and spilled in split mode).
+template <int PREC, int KS, int MI>
 __global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
-    constexpr int BM = 128, TB = 4, NPL = PREC ? 2 : 1;
+    constexpr int BM = 128 * MI, TB = 4, NPL = PREC ? 2 : 1;
     constexpr int ALD = KS + 8;                            // slab row stride (bf16)
     constexpr int BLD = TB * KS + 8;                       // weight stage row stride (bf16)
     constexpr int CPR = KS / 8;                            // 16-byte chunks per slab row
@@ -781,40 +784,49 @@ __global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
     __syncthreads();                                       // zero fill before the first stage lands on top of it
     bload(0);
     bstore();
-    f32x16 acc[1][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int nst = taps / TB;
     for (int st = 0; st < nst; ++st) {
         __syncthreads();                                   // stage st (and, first time, the slab) is in LDS
         if (st + 1 < nst) bload(st + 1);
 #pragma unroll
         for (int tp = 0; tp < TB; ++tp) {
-            const unsigned short* pa = sA + (wave * 32 + lr + st * TB + tp) * ALD + lh * 8;
+            const unsigned short* pa = sA + (wave * (32 * MI) + lr + st * TB + tp) * ALD + lh * 8;
             const unsigned short* pb = sB + lr * BLD + tp * KS + lh * 8;
 #pragma unroll
             for (int ks = 0; ks < KS / 16; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
-                bf16x8 al;
-                if (PREC) al = *reinterpret_cast<const bf16x8*>(pa + srows * ALD + ks * 16);
+                bf16x8 ah[MI], al[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * ALD + ks * 16);
+                    if (PREC) al[i] = *reinterpret_cast<const bf16x8*>(pa + (srows + i * 32) * ALD + ks * 16);
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pb + j * 32 * BLD + ks * 16);
-                    if (PREC) {
-                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pb + (64 + j * 32) * BLD + ks * 16);
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[0][j], 0, 0, 0);
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[0][j], 0, 0, 0);
+                    bf16x8 bl;
+                    if (PREC) bl = *reinterpret_cast<const bf16x8*>(pb + (64 + j * 32) * BLD + ks * 16);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        if (PREC) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
                     }
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[0][j], 0, 0, 0);
                 }
             }
         }
         __syncthreads();                                   // every wave is done with stage st
         if (st + 1 < nst) bstore();
     }
-    epilogue<2, 1>(d, acc, m0 + wave * 32 + 4 * lh, lr, z1, z2);
+    epilogue<2, MI>(d, acc, m0 + wave * (32 * MI) + 4 * lh, lr, z1, z2);
 }
 
 // resident workgroups of a kernel on this device (CUs x occupancy), cached per kernel
@@ -911,18 +923,23 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         d.ldb >= d.K && d.a_kseg_stride == d.lda) {
         const int taps = d.K / d.a_kseg;
         const int npl = d.precision ? 2 : 1;
-        const size_t lds = 2 * (size_t)npl * ((size_t)(128 + taps - 1) * (d.a_kseg + 8) + 64 * (size_t)(4 * d.a_kseg + 8));
+        // 256-row tiles (64 rows per wave) for wav2vec2-base's 48-channel groups when the clip has more than 128 rows
+        const int mi = (d.a_kseg == 48 && d.M > 128) ? 2 : 1;
+        const size_t lds = 2 * (size_t)npl * ((size_t)(128 * mi + taps - 1) * (d.a_kseg + 8) + 64 * (size_t)(4 * d.a_kseg + 8));
         if (lds <= 150 * 1024) {
-            dim3 wgrid(cdiv(d.M, 128), d.batch);
-#define PAA_WIN(P, KS_)                                                                                                      \
+            dim3 wgrid(cdiv(d.M, 128 * mi), d.batch);
+#define PAA_WIN(P, KS_, MI_)                                                                                                 \
             {                                                                                                                \
                 static bool attr = false;                                                                                    \
-                if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<P, KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
-                hipLaunchKernelGGL((k_gemm_win<P, KS_>), wgrid, dim3(256), lds, st, g, taps);                                \
+                if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<P, KS_, MI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
+                hipLaunchKernelGGL((k_gemm_win<P, KS_, MI_>), wgrid, dim3(256), lds, st, g, taps);                           \
             }
             if (prof) { g_prof.variant[g_prof.n] = 40 + (d.precision ? 4 : 0); }
-            if (d.a_kseg == 48) { if (d.precision) PAA_WIN(1, 48) else PAA_WIN(0, 48) }
-            else { if (d.precision) PAA_WIN(1, 64) else PAA_WIN(0, 64) }
+            if (d.a_kseg == 48) {
+                if (mi == 2) { if (d.precision) PAA_WIN(1, 48, 2) else PAA_WIN(0, 48, 2) }
+                else { if (d.precision) PAA_WIN(1, 48, 1) else PAA_WIN(0, 48, 1) }
+            }
+            else { if (d.precision) PAA_WIN(1, 64, 1) else PAA_WIN(0, 64, 1) }
 #undef PAA_WIN
             if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }
             PAA_LAUNCH_CHECK();

@@ -181,7 +181,7 @@ def test_gemm_bf16_operands(prec):
              bias_s2=Hg, act=1, ld_res=H, res_s1=P * H, res_s2=Hg)
     _bf_case("window", d, dict(A=B * P * H, B=G * Hg * Kt * Hg, C=B * P * H, bias=H, C_pre=B * P * H, residual=B * P * H), prec)
     # grouped positional conv in its slab-kernel form (a_kseg 48 / 64, taps % 4 == 0), forward and dgrad padding
-    for Hg, Kt, T, pad in ((48, 8, 150, 4), (48, 16, 300, 7), (64, 8, 131, 4)):
+    for Hg, Kt, T, pad in ((48, 8, 150, 4), (48, 16, 300, 7), (48, 8, 100, 3), (48, 128, 499, 64), (64, 8, 131, 4)):
         B, G, P = 2, 2, T + 1
         H = G * Hg
         d = dict(M=T, N=Hg, K=Kt * Hg, lda=H, ldb=Kt * Hg, ldc=H, a_kseg=Hg, a_kseg_stride=H, a_window=1, a_pad=pad,
