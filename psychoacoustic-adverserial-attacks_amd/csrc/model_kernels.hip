@@ -6,6 +6,7 @@
 //   Wav2Vec2GroupNormConvLayer / Wav2Vec2LayerNormConvLayer (:275-323), nn.LayerNorm, softmax,
 //   F.ctc_loss(reduction='sum', zero_infinity=False) and its backward.
 #include <cstdlib>
+#include <type_traits>
 
 #include "model_kernels.h"
 
@@ -1049,7 +1050,11 @@ __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ lab
         if (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l[j]) skb |= 1u << j;
         if (wave == 0) w.lab[j * 64 + lane] = s < SP ? l[j] : -1;
     }
-    const bool fwd = wave == 0;
+    // the direction is a compile-time constant inside the recursion (one instantiation per wave): with a run-time flag the
+    // time loop carried ~30 selects and as many register moves per frame on its serial chain
+    int esum_out = 0;
+    auto recursion = [&](auto dir) {
+    constexpr bool fwd = decltype(dir)::value;
     double* rows = fwd ? w.arow : w.brow;
     int* ecc = fwd ? w.ea : w.eb;
     double a[NS];
@@ -1125,13 +1130,16 @@ __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ lab
             if (s == SP - 2) s_pend[1] = a[j];
         }
     }
+    esum_out = esum;
+    };
+    if (wave == 0) recursion(std::true_type{}); else recursion(std::false_type{});
     __syncthreads();
     if (tid == 0) {
         const double phat = s_pend[0] + s_pend[1];
         *w.phat = phat;
-        w.tail[0] = esum;                 // thread 0 is lane 0 of the alpha wave: EA_{T-1}
+        w.tail[0] = esum_out;             // thread 0 is lane 0 of the alpha wave: EA_{T-1}
         w.tail[1] = SP;
-        nll_out[b] = phat > 0.0 ? (float)(-(log(phat) + (double)esum * 0.69314718055994530942)) : INFINITY;
+        nll_out[b] = phat > 0.0 ? (float)(-(log(phat) + (double)esum_out * 0.69314718055994530942)) : INFINITY;
     }
 }
 
