@@ -1060,9 +1060,18 @@ __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ lab
     double a[NS];
     float em[NS], emn[NS];
     int esum = 0;
+    // branch-free inner step: states past the end read the blank's probability and multiply it by 0 (l[j] = blank
+    // there), and the skip transition enters through fma(v2, 0.0 | 1.0, v) — bit-identical to the selects they replace
+    float vm[NS];
+    double skm[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        vm[j] = (lane * NS + j < SP) ? 1.f : 0.f;
+        skm[j] = ((fwd ? skf : skb) & (1u << j)) ? 1.0 : 0.0;
+    }
     auto emis = [&](int t, float (&e)[NS]) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) e[j] = (lane * NS + j < SP) ? ytab[(size_t)t * V + l[j]] : 0.f;
+        for (int j = 0; j < NS; ++j) e[j] = ytab[(size_t)t * V + l[j]] * vm[j];
     };
     // exact power-of-two normalisation (every 4th step: a step shrinks a row by at most 2^-149, far inside the f64
     // exponent range over 4 steps), then store the row and the exponent it is scaled by
@@ -1110,11 +1119,11 @@ __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ lab
             if (fwd) {
                 v += j >= 1 ? a[j >= 1 ? j - 1 : 0] : n1;
                 const double v2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? n1 : n2);
-                if (skf & (1u << j)) v += v2;
+                v = fma(v2, skm[j], v);
             } else {
                 v += j + 1 < NS ? a[j + 1 < NS ? j + 1 : 0] : n1;
                 const double v2 = j + 2 < NS ? a[j + 2 < NS ? j + 2 : 0] : (j + 2 == NS ? n1 : n2);
-                if (skb & (1u << j)) v += v2;
+                v = fma(v2, skm[j], v);
             }
             nw[j] = v * (double)em[j];
         }
