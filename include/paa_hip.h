@@ -85,6 +85,8 @@ paa_status paa_istft(paa_proj* h, const float* d_S, int B, int T, float* d_out, 
 
 /* train.py:160-161  p += lr * sign(grad). */
 paa_status paa_sign_step(float* d_p, const float* d_grad, float lr, int L, void* stream);
+/* core/projections.py:37-39 project_linf(p, min_val, max_val): in-place clamp of n floats to [lo, hi]. */
+paa_status paa_clamp(float* d_p, int64_t n, float lo, float hi, void* stream);
 /* train.py:136  out = clamp(clean + p, -1, 1), p broadcast over the batch. */
 paa_status paa_compose_clamp(const float* d_clean, const float* d_p, float* d_out, int B, int L, void* stream);
 
@@ -122,8 +124,10 @@ int paa_model_frames(const paa_model* m);     /* T_e for the configured length *
  * evaluation.py:16 semantics], d_labels (B, S_max) int32 with negatives as padding.
  *   d_grad  (L)  out: sum_b mask_b * dLoss/dperturbed_b, times `direction`   (train.py:158) — NULL => forward only
  *   d_logits (B, T_e, V) out (may be NULL)
- *   d_stats  (8) out: [0] loss (sum over the batch, HF ctc_loss_reduction='sum'), [1] sum clean^2,
- *            [2] TV(clean), rest reserved — the quantities a data-parallel run all-reduces with d_grad.
+ *   d_stats  (8) out: [0] loss (sum over the batch, HF ctc_loss_reduction='sum').  Slots [1..7] are NOT written by
+ *            this call: they belong to the caller's data-parallel bookkeeping (paa_amd/training_utils/pgd.py packs
+ *            [1] sum clean^2 and [2] TV(clean) from paa_batch_stats, [3] WER word errors, [4] WER reference words,
+ *            [5] local clean element count behind the gradient so that ONE all-reduce carries everything).
  */
 paa_status paa_model_fwd_bwd(paa_model* m, const float* d_clean, const float* d_p, const int32_t* d_labels,
                              int B, int S_max, int direction, float* d_grad, float* d_logits, float* d_stats,
@@ -133,6 +137,10 @@ paa_status paa_model_fwd_bwd(paa_model* m, const float* d_clean, const float* d_
  * without clamping as the reference's evaluation does (evaluation.py:16); d_p may be NULL (clean evaluation). */
 paa_status paa_model_forward(paa_model* m, const float* d_clean, const float* d_p, int clamp, const int32_t* d_labels,
                              int B, int S_max, float* d_logits, float* d_stats, void* stream);
+
+/* core/loss_helpers.py:26,61  pred_ids = torch.argmax(logits, dim=-1): d_logits (rows, V) f32 -> d_ids (rows) int16
+ * (first maximum wins; a NaN counts as the maximum, as in torch).  Feeds the host-side greedy CTC decode / WER. */
+paa_status paa_argmax_ids(const float* d_logits, int64_t rows, int V, int16_t* d_ids, void* stream);
 
 /* Diagnostics for tests: synchronous copy of a named internal activation to the host (see csrc/model.hip);
  * returns the number of floats the buffer holds for batch B (0 = unknown name, <0 = HIP error). */

@@ -66,6 +66,7 @@ _SIGS = {
     "paa_stft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "paa_istft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "paa_sign_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "paa_clamp": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
     "paa_compose_clamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "paa_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(PaaArch), C.POINTER(PaaTensor), C.c_int, C.c_int,
                                    C.c_int, C.c_int]),
@@ -76,6 +77,7 @@ _SIGS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "paa_model_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "paa_argmax_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "paa_model_debug_read": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int]),
     "paa_model_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "paa_gemm": (C.c_int, [C.POINTER(PaaGemmDesc), C.c_void_p]),

@@ -54,15 +54,35 @@ def get_loss_for_training(model, data, target_texts, processor, args):
     return r["loss"], r["logits"]
 
 
-get_loss = get_loss_for_training          # loss_helpers.py:46-57 is the same computation
+def get_loss(batch_waveforms, target_texts, processor, args, model):
+    """loss_helpers.py:46-57 — the evaluation twin of ``get_loss_for_training`` with the reference's argument
+    order ``(batch_waveforms, target_texts, processor, args, model)``; same computation."""
+    return get_loss_for_training(model, batch_waveforms, target_texts, processor, args)
 
 
 def get_logits(batch_waveforms, processor, args, model):
-    """loss_helpers.py:34-43 applies the processor's per-utterance zero-mean / unit-variance
-    normalisation before the forward; that normalisation is done here with torch on the device."""
-    x = batch_waveforms.to(model.device, torch.float32)
-    x = (x - x.mean(dim=-1, keepdim=True)) / torch.sqrt(x.var(dim=-1, keepdim=True, unbiased=False) + 1e-7)
+    """loss_helpers.py:34-43: the only place the reference applies the processor's feature extractor, i.e.
+    ``Wav2Vec2FeatureExtractor(do_normalize=True)``: per-utterance zero mean / unit variance,
+    ``(x - mean) / sqrt(var + 1e-7)`` with the population variance (HF feature_extraction_wav2vec2.py
+    ``zero_mean_unit_var_norm``).  A processor object, when given, is used as is (host round trip, as the
+    reference does); otherwise the same normalisation runs on the device."""
+    if processor is not None:
+        inputs = processor(batch_waveforms.cpu().tolist(), sampling_rate=args.sr, return_tensors="pt", padding=True)
+        x = inputs.input_values.to(model.device, torch.float32)
+    else:
+        x = batch_waveforms.to(model.device, torch.float32)
+        x = (x - x.mean(dim=-1, keepdim=True)) / torch.sqrt(x.var(dim=-1, keepdim=True, unbiased=False) + 1e-7)
     return model.forward(x.contiguous(), None, None)["logits"]
+
+
+def argmax_ids(logits: torch.Tensor) -> torch.Tensor:
+    """``torch.argmax(logits, dim=-1)`` (loss_helpers.py:26,61) through the C ABI: (..., V) f32 cuda -> (...) int16."""
+    from .. import _lib, runtime
+    x = runtime.as_f32_cuda(logits, "logits")
+    ids = torch.empty(x.shape[:-1], dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().paa_argmax_ids(_lib.ptr(x), ids.numel(), x.shape[-1], _lib.ptr(ids), _lib.stream_ptr()))
+    return ids
 
 
 def greedy_decode_ids(pred_ids) -> list:
@@ -99,9 +119,9 @@ def wer_counts(pred_texts, ref_texts):
 
 def compute_wer(logits, target_texts, processor, wer_metric):
     """loss_helpers.py:25-32."""
-    pred_ids = torch.argmax(logits, dim=-1)
+    pred_ids = argmax_ids(logits)
     if processor is not None:
-        pred_texts = processor.batch_decode(pred_ids, skip_special_tokens=True)
+        pred_texts = processor.batch_decode(pred_ids.long().cpu(), skip_special_tokens=True)
     else:
         pred_texts = greedy_decode_ids(pred_ids.tolist())
     pred_texts = [p.strip().lower() for p in pred_texts]
@@ -114,7 +134,7 @@ def compute_wer(logits, target_texts, processor, wer_metric):
 
 def decode(logits, processor):
     """loss_helpers.py:60-62."""
-    pred_ids = torch.argmax(logits, dim=-1)
+    pred_ids = argmax_ids(logits)
     if processor is not None:
-        return processor.batch_decode(pred_ids)
+        return processor.batch_decode(pred_ids.long().cpu())
     return greedy_decode_ids(pred_ids.tolist())

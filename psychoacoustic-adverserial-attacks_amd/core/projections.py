@@ -30,10 +30,12 @@ def project_snr(clean, perturbation, snr_db):
 
 
 def project_linf(p, min_val, max_val):
-    """projections.py:37-39 (the dispatcher always passes a symmetric box, train.py:87)."""
-    if float(min_val) != -float(max_val):
-        raise ValueError("project_linf: only the symmetric box [-eps, +eps] is supported")
-    return _project(p, None, "linf", linf_size=float(max_val))
+    """projections.py:37-39: ``torch.clamp(p, min_val, max_val)`` — any box, not only the symmetric one the
+    dispatcher passes (train.py:87)."""
+    q = runtime.as_f32_cuda(p, "p").clone()
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().paa_clamp(_lib.ptr(q), q.numel(), float(min_val), float(max_val), _lib.stream_ptr()))
+    return q
 
 
 def project_l2(p, epsilon):

@@ -69,6 +69,22 @@ __global__ void k_copy_logits(const float* __restrict__ src, float* __restrict__
     }
 }
 
+// greedy CTC ids (loss_helpers.py:26 / :61, torch.argmax(logits, -1)): one thread per frame, first maximum wins, a NaN
+// counts as the maximum (torch semantics)
+__global__ void k_argmax_ids(const float* __restrict__ x, int64_t rows, int V, int16_t* __restrict__ ids) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* row = x + r * V;
+    float best = row[0];
+    int bi = 0;
+    for (int c = 1; c < V; ++c) {
+        const float v = row[c];
+        if (best != best) break;
+        if (v > best || v != v) { best = v; bi = c; }
+    }
+    ids[r] = (int16_t)bi;
+}
+
 // out = dy * gelu'(pre)   (f32 and / or bf16 planes)
 __global__ void k_mul_gelu_grad(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ out,
                                 Bf outb, int64_t n) {
@@ -623,6 +639,15 @@ extern "C" paa_status paa_model_forward(paa_model* m, const float* d_clean, cons
         PAA_TRY(ctc(m->logits, d_labels, B, m->T, m->P, V, S_max, m->a.blank, 1.f, m->nll, nullptr, NOBF, m->ctc_work, st));
         if (d_stats) PAA_TRY(sum_small(m->nll, B, d_stats, st));
     }
+    return PAA_OK;
+}
+
+// torch.argmax(logits, dim=-1) of core/loss_helpers.py:26,61 on a caller-owned (rows, V) f32 tensor -> int16 ids.
+extern "C" paa_status paa_argmax_ids(const float* d_logits, int64_t rows, int V, int16_t* d_ids, void* stream) {
+    if (!d_logits || !d_ids) PAA_FAIL(PAA_ERR_ARG, "paa_argmax_ids: null argument");
+    if (rows < 1 || V < 1 || V > 32767) PAA_FAIL(PAA_ERR_SIZE, "paa_argmax_ids: rows=%lld V=%d", (long long)rows, V);
+    hipLaunchKernelGGL(k_argmax_ids, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, d_logits, rows, V, d_ids);
+    PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
 

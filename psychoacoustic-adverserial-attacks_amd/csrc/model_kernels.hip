@@ -928,103 +928,105 @@ __global__ __launch_bounds__(512) void k_ctc(const float* __restrict__ logits, c
 }
 
 // ---- wave-synchronous CTC (label capacity 2 S_max + 1 <= 1024) ----------------------------------------------------------
-// The recursions run in the PROBABILITY domain in float64 with exact power-of-two rescaling instead of the log domain:
-// no exp / log inside the time loop, and no workgroup barrier either — one wave runs alpha forwards, a second wave runs
-// beta backwards, each lane owning NS consecutive states of the extended label sequence in registers; a step needs the
-// two boundary states of the neighbouring lane (shuffles) and the emission probabilities y_t(l_s) (gathered from the
-// frame's softmax row, staged one step ahead).  After every step the row is scaled by 2^-E, E = the largest binary
-// exponent in the row (integer wave maximum through DPP): scaling by powers of two is exact, so the schedule cannot
-// change a single bit of the result, and the cumulative exponents EA_t / EB_t are integers.
-//   log P = log(ahat_{T-1}(S'-1) + ahat_{T-1}(S'-2)) + EA_{T-1} ln 2
-//   gamma_t(s) = ahat_t(s) bhat_t(s) / y_t(l_s) * 2^(EA_t + EB_t - EA_{T-1}) / Phat        (posterior occupancy)
-// so the gradient phase needs no reduction either: one wave per frame, fixed-point LDS atomics per class (order
-// independent => bitwise reproducible), dlogits[t][c] = scale * (y_t(c) - sum_{s: l_s = c} gamma_t(s)).
-__device__ __forceinline__ int wave_max_i32(int v) {
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));    // row_half_mirror
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));    // row_mirror
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
+// One wave runs alpha forwards, a second wave runs beta backwards, each lane owning NS consecutive states of the extended
+// label sequence in registers: no workgroup barrier in the time loop, the two boundary states of the neighbouring lane
+// arrive by DPP wave shifts, the emission log-probabilities of the next frame are fetched one step ahead.  The recursion
+// is in the LOG domain and therefore total: any target the frame count admits gets a finite loss whatever the dynamic
+// range of the posteriors (a probability-domain recursion rescaled by the row maximum — the previous version of this
+// kernel — flushes states more than 2^-1074 below the best state of a frame, which on peaked logits is where the whole
+// target path lives).  States are float64; only the bounded correction log(sum_i exp(x_i - max)) in
+// [0, log 3] goes through the float32 hardware exp2 / log2 (absolute error ~1e-7 per step).  Unreachable states hold
+// the finite sentinel CTC_NEG = -1e30 instead of -inf: it absorbs every finite addend exactly, so the step is
+// branch-free (skip transitions and states past the end of the sequence enter as "+ 0 or + CTC_NEG").
+//   nll = -log(exp(alpha_{T-1}(S'-1)) + exp(alpha_{T-1}(S'-2)))
+//   gamma_t(s) = exp(alpha_t(s) + beta_t(s) + nll - lp_t(l_s))                               (posterior occupancy)
+// The gradient phase needs no reduction: one wave per frame, fixed-point LDS atomics per class (order independent =>
+// bitwise reproducible), dlogits[t][c] = scale * (softmax_t(c) - sum_{s: l_s = c} gamma_t(s)).
+constexpr double CTC_NEG = -1.0e30;
 
-// Per-clip work layout (floats): y [T][V] | ahat [T][64 NS] f64 | bhat [T][64 NS] f64 | EA [T] i32 | EB [T] i32 |
-// lab [64 NS] i32 (lab[j * 64 + lane] = label of state lane * NS + j, -1 past the end) | Phat f64, EA_{T-1} i32, S' i32
+// Per-clip work layout (floats): lp [T][V] f64 | alpha [T][64 NS] f64 | beta [T][64 NS] f64 | nll f64 |
+// lab [64 NS] i32 (lab[j * 64 + lane] = label of state lane * NS + j, -1 past the end)
 struct CtcWork {
-    float* y; double* arow; double* brow; int* ea; int* eb; int* lab; double* phat; int* tail;
+    double* lp; double* arow; double* brow; double* nll; int* lab;
 };
 __device__ __forceinline__ CtcWork ctc_work(float* wk, int T, int V, int row) {
     CtcWork w;
-    w.y = wk;
-    w.arow = reinterpret_cast<double*>(wk + (((size_t)T * V + 1) & ~(size_t)1));
+    w.lp = reinterpret_cast<double*>(wk);
+    w.arow = w.lp + (size_t)T * V;
     w.brow = w.arow + (size_t)T * row;
-    w.ea = reinterpret_cast<int*>(w.brow + (size_t)T * row);
-    w.eb = w.ea + ((T + 1) & ~1);
-    w.lab = w.eb + ((T + 1) & ~1);
-    w.phat = reinterpret_cast<double*>(w.lab + row);
-    w.tail = reinterpret_cast<int*>(w.phat + 1);
+    w.nll = w.brow + (size_t)T * row;
+    w.lab = reinterpret_cast<int*>(w.nll + 1);
     return w;
 }
 
-// softmax of every frame of every clip: 32 lanes per frame, 8 frames per workgroup
-__global__ __launch_bounds__(256) void k_ctc_softmax(const float* __restrict__ logits, int B, int T, int Tpad, int V,
-                                                     float* __restrict__ work, int64_t wpc) {
+// log-softmax of every frame of every clip in float64 (from float32 max / sum-exp pieces): 32 lanes per frame
+__global__ __launch_bounds__(256) void k_ctc_logsoftmax(const float* __restrict__ logits, int B, int T, int Tpad, int V,
+                                                        float* __restrict__ work, int64_t wpc) {
     const int f = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (f >= B * T) return;
     const int b = f / T, t = f - b * T, c = threadIdx.x & 31;
     const float* lg = logits + ((size_t)b * Tpad + t) * V;
-    float* y = work + (size_t)b * wpc + (size_t)t * V;
+    double* lp = reinterpret_cast<double*>(work + (size_t)b * wpc) + (size_t)t * V;
     float mx = -INFINITY;
     for (int cc = c; cc < V; cc += 32) mx = fmaxf(mx, lg[cc]);
     for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
     float se = 0.f;
     for (int cc = c; cc < V; cc += 32) se += __expf(lg[cc] - mx);
     for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 32);
-    const float inv = 1.0f / se;
-    for (int cc = c; cc < V; cc += 32) y[cc] = __expf(lg[cc] - mx) * inv;
+    const double lz = (double)mx + (double)__logf(se);
+    for (int cc = c; cc < V; cc += 32) lp[cc] = (double)lg[cc] - lz;
 }
 
-// the two recursions of one clip: wave 0 alpha, wave 1 beta; LDS_TAB: the clip's y table is first copied to LDS
 // whole-wave shift by one lane through DPP (gfx9 wave_shr / wave_shl): lane i receives lane i-1 (i+1); the first (last)
-// lane receives 0.  A few cycles instead of the ~120-cycle LDS round trip of ds_bpermute, on the serial chain of a step.
+// lane keeps `old` = CTC_NEG (bound_ctrl off).  A few cycles instead of the ~120-cycle LDS round trip of ds_bpermute.
 __device__ __forceinline__ double wave_shr1(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(CTC_NEG), __double2loint(v), 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(CTC_NEG), __double2hiint(v), 0x138, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_shl1(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(CTC_NEG), __double2loint(v), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(CTC_NEG), __double2hiint(v), 0x130, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// log(exp(x0) + exp(x1) + exp(x2)), float64 in / out, float32 hardware transcendentals on the bounded part
+__device__ __forceinline__ double ctc_lse3(double x0, double x1, double x2) {
+    const double m = fmax(x0, fmax(x1, x2));
+    const float s = __builtin_amdgcn_exp2f((float)(x0 - m) * 1.44269504088896341f) +
+                    __builtin_amdgcn_exp2f((float)(x1 - m) * 1.44269504088896341f) +
+                    __builtin_amdgcn_exp2f((float)(x2 - m) * 1.44269504088896341f);
+    return m + (double)(__builtin_amdgcn_logf(s) * 0.69314718055994531f);
+}
 
+// the two recursions of one clip: wave 0 alpha, wave 1 beta; LDS_TAB: the clip's lp table is first copied to LDS
 template <int NS, bool LDS_TAB>
 __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ labels, int T, int V, int S_max, int blank,
                                                  float* __restrict__ nll_out, float* __restrict__ work, int64_t wpc) {
-    extern __shared__ __attribute__((aligned(16))) float smf[];
+    extern __shared__ __attribute__((aligned(16))) double smd[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int SPmax = 2 * S_max + 1;
     constexpr int ROW = 64 * NS;
     const CtcWork w = ctc_work(work + (size_t)b * wpc, T, V, ROW);
-    int* lab = reinterpret_cast<int*>(smf + (LDS_TAB ? (((size_t)T * V + 3) & ~(size_t)3) : 0));      // [SPmax] extended labels
+    int* lab = reinterpret_cast<int*>(smd + (LDS_TAB ? (size_t)T * V : 0));      // [SPmax] extended labels
     __shared__ int s_len;
-    __shared__ double s_pend[2];
     // extended labels: valid labels are the non-negative entries, in order (HF masked_select).  The label row is first
     // copied to LDS by all threads (one global round trip instead of S_max dependent ones), then compacted by thread 0.
     int* raw = lab + SPmax;                                       // [S_max]
     for (int s = tid; s < S_max; s += 128) raw[s] = labels[(size_t)b * S_max + s];
-    if (LDS_TAB) {          // y table -> LDS, 8 independent 16-byte loads in flight per thread
-        const int n4 = T * V / 4;
-        const float4* src = reinterpret_cast<const float4*>(w.y);
-        float4* dst = reinterpret_cast<float4*>(smf);
-        for (int i0 = 0; i0 < n4; i0 += 128 * 8) {
-            float4 v[8];
+    if (LDS_TAB) {          // lp table -> LDS, 8 independent 16-byte loads in flight per thread
+        const int n2 = T * V / 2;
+        const double2* src = reinterpret_cast<const double2*>(w.lp);
+        double2* dst = reinterpret_cast<double2*>(smd);
+        const int nfull = n2 / (128 * 8) * (128 * 8);       // whole rounds carry no bounds checks (keeps v[] in registers)
+        for (int i0 = 0; i0 < nfull; i0 += 128 * 8) {
+            double2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 128 + tid; if (i < n4) v[u] = src[i]; }
+            for (int u = 0; u < 8; ++u) v[u] = src[i0 + u * 128 + tid];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 128 + tid; if (i < n4) dst[i] = v[u]; }
+            for (int u = 0; u < 8; ++u) dst[i0 + u * 128 + tid] = v[u];
         }
-        for (int i = n4 * 4 + tid; i < T * V; i += 128) smf[i] = w.y[i];
+        for (int i = nfull + tid; i < n2; i += 128) dst[i] = src[i];
+        if (((T * V) & 1) && tid == 0) smd[T * V - 1] = w.lp[T * V - 1];
     }
     __syncthreads();
     if (tid == 0) {
@@ -1035,9 +1037,8 @@ __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ lab
             if (v >= 0) { lab[2 * k + 1] = v; lab[2 * k + 2] = blank; ++k; }
         }
         s_len = k;
-        s_pend[0] = 0.0; s_pend[1] = 0.0;
     }
-    const float* ytab = LDS_TAB ? smf : w.y;
+    const double* tab = LDS_TAB ? smd : w.lp;
     __syncthreads();
     const int S = s_len, SP = 2 * S + 1;
     int l[NS];
@@ -1050,106 +1051,78 @@ __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ lab
         if (s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l[j]) skb |= 1u << j;
         if (wave == 0) w.lab[j * 64 + lane] = s < SP ? l[j] : -1;
     }
-    // the direction is a compile-time constant inside the recursion (one instantiation per wave): with a run-time flag the
-    // time loop carried ~30 selects and as many register moves per frame on its serial chain
-    int esum_out = 0;
+    // the direction is a compile-time constant inside the recursion (one instantiation per wave)
     auto recursion = [&](auto dir) {
-    constexpr bool fwd = decltype(dir)::value;
-    double* rows = fwd ? w.arow : w.brow;
-    int* ecc = fwd ? w.ea : w.eb;
-    double a[NS];
-    float em[NS], emn[NS];
-    int esum = 0;
-    // branch-free inner step: states past the end read the blank's probability and multiply it by 0 (l[j] = blank
-    // there), and the skip transition enters through fma(v2, 0.0 | 1.0, v) — bit-identical to the selects they replace
-    float vm[NS];
-    double skm[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        vm[j] = (lane * NS + j < SP) ? 1.f : 0.f;
-        skm[j] = ((fwd ? skf : skb) & (1u << j)) ? 1.0 : 0.0;
-    }
-    auto emis = [&](int t, float (&e)[NS]) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) e[j] = ytab[(size_t)t * V + l[j]] * vm[j];
-    };
-    // exact power-of-two normalisation (every 4th step: a step shrinks a row by at most 2^-149, far inside the f64
-    // exponent range over 4 steps), then store the row and the exponent it is scaled by
-    auto finish_row = [&](int t, bool norm) {
-        if (norm) {
-            double mx = a[0];
-#pragma unroll
-            for (int j = 1; j < NS; ++j) mx = fmax(mx, a[j]);
-            const int e = wave_max_i32(mx > 0.0 ? __builtin_amdgcn_frexp_exp(mx) : -100000);
-            if (e > -100000) {
-#pragma unroll
-                for (int j = 0; j < NS; ++j) a[j] = __builtin_amdgcn_ldexp(a[j], -e);
-                esum += e;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NS; ++j) rows[(size_t)t * ROW + j * 64 + lane] = a[j];
-        if (lane == 0) ecc[t] = esum;
-    };
-    const int t0 = fwd ? 0 : T - 1;
-    emis(t0, em);
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = lane * NS + j;
-        const bool on = fwd ? (s == 0 || s == 1) : (s == SP - 1 || s == SP - 2);
-        a[j] = (on && s < SP) ? (double)em[j] : 0.0;
-    }
-    finish_row(t0, true);
-    if (T > 1) emis(fwd ? 1 : T - 2, em);
-    for (int i = 1; i < T; ++i) {
-        const int t = fwd ? i : T - 1 - i;
-        if (i + 1 < T) emis(fwd ? i + 1 : T - 2 - i, emn);      // next step's emissions fly under this step
-        double n1, n2;                                          // the neighbour lane's two boundary states
-        if (fwd) {
-            n1 = wave_shr1(a[NS - 1]);
-            n2 = NS >= 2 ? wave_shr1(a[NS >= 2 ? NS - 2 : 0]) : wave_shr1(n1);
-        } else {
-            n1 = wave_shl1(a[0]);
-            n2 = NS >= 2 ? wave_shl1(a[NS >= 2 ? 1 : 0]) : wave_shl1(n1);
-        }
-        double nw[NS];
+        constexpr bool fwd = decltype(dir)::value;
+        double* rows = fwd ? w.arow : w.brow;
+        double a[NS], em[NS], emn[NS];
+        double skn[NS], dead[NS];                  // additive masks: 0 or CTC_NEG
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            double v = a[j];
-            if (fwd) {
-                v += j >= 1 ? a[j >= 1 ? j - 1 : 0] : n1;
-                const double v2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? n1 : n2);
-                v = fma(v2, skm[j], v);
-            } else {
-                v += j + 1 < NS ? a[j + 1 < NS ? j + 1 : 0] : n1;
-                const double v2 = j + 2 < NS ? a[j + 2 < NS ? j + 2 : 0] : (j + 2 == NS ? n1 : n2);
-                v = fma(v2, skm[j], v);
-            }
-            nw[j] = v * (double)em[j];
+            dead[j] = (lane * NS + j < SP) ? 0.0 : CTC_NEG;
+            skn[j] = ((fwd ? skf : skb) & (1u << j)) ? 0.0 : CTC_NEG;
         }
+        auto emis = [&](int t, double (&e)[NS]) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) { a[j] = nw[j]; em[j] = emn[j]; }
-        finish_row(t, (i & 3) == 0);
-    }
-    if (fwd) {           // Phat = ahat_{T-1}(S'-1) + ahat_{T-1}(S'-2)
+            for (int j = 0; j < NS; ++j) e[j] = tab[(size_t)t * V + l[j]] + dead[j];
+        };
+        auto store_row = [&](int t) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) rows[(size_t)t * ROW + j * 64 + lane] = a[j];
+        };
+        const int t0 = fwd ? 0 : T - 1;
+        emis(t0, em);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int s = lane * NS + j;
-            if (s == SP - 1) s_pend[0] = a[j];
-            if (s == SP - 2) s_pend[1] = a[j];
+            const bool on = fwd ? (s == 0 || s == 1) : (s == SP - 1 || s == SP - 2);
+            a[j] = (on && s < SP) ? em[j] : CTC_NEG;
         }
-    }
-    esum_out = esum;
+        store_row(t0);
+        if (T > 1) emis(fwd ? 1 : T - 2, em);
+        for (int i = 1; i < T; ++i) {
+            const int t = fwd ? i : T - 1 - i;
+            if (i + 1 < T) emis(fwd ? i + 1 : T - 2 - i, emn);      // next step's emissions fly under this step
+            double n1, n2;                                          // the neighbour lane's two boundary states
+            if (fwd) {
+                n1 = wave_shr1(a[NS - 1]);
+                n2 = NS >= 2 ? wave_shr1(a[NS >= 2 ? NS - 2 : 0]) : wave_shr1(n1);
+            } else {
+                n1 = wave_shl1(a[0]);
+                n2 = NS >= 2 ? wave_shl1(a[NS >= 2 ? 1 : 0]) : wave_shl1(n1);
+            }
+            double nw[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                double x1, x2;
+                if (fwd) {
+                    x1 = j >= 1 ? a[j >= 1 ? j - 1 : 0] : n1;
+                    x2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? n1 : n2);
+                } else {
+                    x1 = j + 1 < NS ? a[j + 1 < NS ? j + 1 : 0] : n1;
+                    x2 = j + 2 < NS ? a[j + 2 < NS ? j + 2 : 0] : (j + 2 == NS ? n1 : n2);
+                }
+                nw[j] = ctc_lse3(a[j], x1, x2 + skn[j]) + em[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) { a[j] = nw[j]; em[j] = emn[j]; }
+            store_row(t);
+        }
+        if (fwd) {           // log P = lse(alpha_{T-1}(S'-1), alpha_{T-1}(S'-2)); both live in one lane or in two neighbours
+            const double prev = wave_shr1(a[NS - 1]);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int s = lane * NS + j;
+                if (s == SP - 1) {
+                    const double l2 = SP >= 2 ? (j >= 1 ? a[j >= 1 ? j - 1 : 0] : prev) : CTC_NEG;
+                    const double nll = -ctc_lse3(a[j], l2, CTC_NEG);
+                    *w.nll = nll;
+                    nll_out[b] = nll < 1e29 ? (float)nll : INFINITY;
+                }
+            }
+        }
     };
     if (wave == 0) recursion(std::true_type{}); else recursion(std::false_type{});
-    __syncthreads();
-    if (tid == 0) {
-        const double phat = s_pend[0] + s_pend[1];
-        *w.phat = phat;
-        w.tail[0] = esum_out;             // thread 0 is lane 0 of the alpha wave: EA_{T-1}
-        w.tail[1] = SP;
-        nll_out[b] = phat > 0.0 ? (float)(-(log(phat) + (double)esum_out * 0.69314718055994530942)) : INFINITY;
-    }
 }
 
 // gradient rows: one wave per frame (grid: frames / 4 x clips)
@@ -1167,32 +1140,28 @@ __global__ __launch_bounds__(256) void k_ctc_grad(int T, int Tpad, int V, float 
         if (t < Tpad) for (int c = lane; c < V; c += 64) { dl[(size_t)t * V + c] = 0.f; store_bf16(dlb, dlo + (size_t)t * V + c, 0.f); }
         return;
     }
-    const double phat = *w.phat;
-    if (!(phat > 0.0)) {                  // infeasible alignment: zero_infinity=False propagates non-finite gradients
+    const double nll = *w.nll;
+    if (!(nll < 1e29)) {                  // infeasible alignment: zero_infinity=False propagates non-finite gradients
         for (int c = lane; c < V; c += 64) { dl[(size_t)t * V + c] = NAN; store_bf16(dlb, dlo + (size_t)t * V + c, NAN); }
         return;
     }
-    const int sh = w.ea[t] + w.eb[t] - w.tail[0];
-    const double invp = 1.0 / phat;
     unsigned* wocc = occs + wave * V;
     for (int c = lane; c < V; c += 64) wocc[c] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const float* y = w.y + (size_t)t * V;
+    const double* lp = w.lp + (size_t)t * V;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const int lj = w.lab[j * 64 + lane];
         if (lj >= 0) {
-            const float yv = y[lj];
-            const double ab = __builtin_amdgcn_ldexp(w.arow[(size_t)t * ROW + j * 64 + lane], sh / 2) *
-                              __builtin_amdgcn_ldexp(w.brow[(size_t)t * ROW + j * 64 + lane], sh - sh / 2);
-            const float g = yv > 0.f ? (float)(ab * invp) * __builtin_amdgcn_rcpf(yv) : 0.f;
+            const double x = w.arow[(size_t)t * ROW + j * 64 + lane] + w.brow[(size_t)t * ROW + j * 64 + lane] + nll - lp[lj];
+            const float g = __expf((float)x);
             const unsigned q = (unsigned)(fminf(g, 2.f) * 1073741824.f + 0.5f);
             if (q) atomicAdd(&wocc[lj], q);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // this wave's LDS atomics before its reads below
     for (int c = lane; c < V; c += 64) {
-        const float gv = gscale * (y[c] - (float)wocc[c] * (1.f / 1073741824.f));
+        const float gv = gscale * (__expf((float)lp[c]) - (float)wocc[c] * (1.f / 1073741824.f));
         dl[(size_t)t * V + c] = gv;
         store_bf16(dlb, dlo + (size_t)t * V + c, gv);
     }
@@ -1202,9 +1171,9 @@ template <int NS>
 static paa_status launch_ctc_ws(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,
                                 float gscale, float* nll, float* dlogits, Bf dlb, float* work, int64_t wpc, hipStream_t st) {
     const int SPmax = 2 * S_max + 1;
-    hipLaunchKernelGGL(k_ctc_softmax, dim3(cdiv((int64_t)B * T, 8)), dim3(256), 0, st, logits, B, T, Tpad, V, work, wpc);
+    hipLaunchKernelGGL(k_ctc_logsoftmax, dim3(cdiv((int64_t)B * T, 8)), dim3(256), 0, st, logits, B, T, Tpad, V, work, wpc);
     PAA_LAUNCH_CHECK();
-    const size_t tab = sizeof(float) * (((size_t)T * V + 3) & ~(size_t)3);
+    const size_t tab = sizeof(double) * (size_t)T * V;
     const size_t small = sizeof(int) * ((size_t)SPmax + S_max) + 64;
     const bool lds_tab = tab + small <= 150 * 1024;
     const size_t lds = small + (lds_tab ? tab : 0);
@@ -1235,13 +1204,13 @@ static int ctc_ws_ns(int SPmax) {
     const int ns = cdiv(SPmax, 64);
     return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 16 ? 16 : 0;
 }
-// work size in floats per clip — log-domain kernel: lp [T][V] + alpha, beta [T][2S+1] doubles;
+// work size in floats per clip — block-level kernel: lp [T][V] + alpha, beta [T][2S+1] doubles;
 // wave-synchronous kernels: see CtcWork
 int64_t ctc_work_floats_per_clip(int T, int V, int S_max) {
     const int64_t SPmax = 2 * (int64_t)S_max + 1;
     const int ns = ctc_ws_ns((int)SPmax);
     if (ns == 0) return 2 * ((int64_t)T * V + 2 * (int64_t)T * SPmax);
-    return (((int64_t)T * V + 1) & ~(int64_t)1) + 4 * (int64_t)T * 64 * ns + 2 * (((int64_t)T + 1) & ~(int64_t)1) + 64 * ns + 16;
+    return 2 * ((int64_t)T * V + 2 * (int64_t)T * 64 * ns + 1) + 64 * ns + 16;
 }
 
 paa_status ctc(const float* logits, const int32_t* labels, int B, int T, int Tpad, int V, int S_max, int blank,

@@ -577,6 +577,16 @@ extern "C" paa_status paa_sign_step(float* d_p, const float* d_grad, float lr, i
     return PAA_OK;
 }
 
+// core/projections.py:37-39 project_linf(p, min_val, max_val) with an arbitrary box (the dispatcher passes +-linf_size).
+extern "C" paa_status paa_clamp(float* d_p, int64_t n, float lo, float hi, void* stream) {
+    if (!d_p) PAA_FAIL(PAA_ERR_ARG, "paa_clamp: null argument");
+    if (n < 1) PAA_FAIL(PAA_ERR_SIZE, "paa_clamp: n=%lld", (long long)n);
+    // lo > hi: every element becomes hi, as torch.clamp documents (min(max(x, lo), hi))
+    hipLaunchKernelGGL(k_clamp, dim3(std::min(cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, d_p, n, lo, hi);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
 extern "C" paa_status paa_compose_clamp(const float* d_clean, const float* d_p, float* d_out, int B, int L, void* stream) {
     if (!d_clean || !d_p || !d_out) PAA_FAIL(PAA_ERR_ARG, "paa_compose_clamp: null argument");
     hipLaunchKernelGGL(k_compose_clamp, dim3(std::min(cdiv((int64_t)B * L, 256), 4096)), dim3(256), 0, (hipStream_t)stream,

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, runtime
 from .arch import Wav2Vec2Arch, pos_conv_weight
 
 
@@ -192,12 +192,31 @@ class PaaModel:
     def from_hf(cls, hf_model, max_batch, length, dtype="bf16", device="cuda"):
         return cls(arch_from_hf_config(hf_model.config), hf_model.state_dict(), max_batch, length, dtype, device)
 
+    def _checked(self, clean, p):
+        """Raw pointers cross the C ABI: refuse anything that is not a contiguous float32 tensor on this model's GPU
+        with the configured length (a float64 / CPU / strided batch would be read as garbage device memory)."""
+        clean = runtime.as_f32_cuda(clean, "clean_audio")
+        if clean.dim() != 2:
+            raise ValueError(f"clean_audio must be (B, L), got {tuple(clean.shape)}")
+        if clean.device != self.device and not (self.device.index is None and clean.device.type == "cuda"):
+            raise RuntimeError(f"clean_audio lives on {clean.device}, the model on {self.device}")
+        if clean.shape[1] != self.length:
+            raise ValueError(f"Loaded perturbation length {clean.shape[1]} != expected {self.length}")
+        if clean.shape[0] < 1 or clean.shape[0] > self.max_batch:
+            raise ValueError(f"batch {clean.shape[0]} exceeds the model's max_batch {self.max_batch}")
+        if p is not None:
+            p = runtime.as_f32_cuda(p, "p")
+            if p.numel() != self.length:
+                raise ValueError(f"Loaded perturbation length {p.numel()} != expected {self.length}")
+            if p.device != clean.device:
+                raise RuntimeError(f"p lives on {p.device}, clean_audio on {clean.device}")
+        return clean, p
+
     def fwd_bwd(self, clean, p, labels, direction=+1, want_grad=True, want_logits=True, out=None):
         """clean (B, L) f32 cuda; p (1, L) or None; labels (B, S) integer tensor, negatives = padding.
         Returns dict(loss=0-d tensor, logits=(B, T_e, V) | None, grad=(1, L) | None, stats=(8,))."""
+        clean, p = self._checked(clean, p)
         B, L = clean.shape
-        if L != self.length:
-            raise ValueError(f"Loaded perturbation length {L} != expected {self.length}")
         dev = self.device
         lab = None if labels is None else labels.to(device=dev, dtype=torch.int32).contiguous()
         S = 0 if lab is None else lab.shape[1]
@@ -219,9 +238,8 @@ class PaaModel:
     def forward(self, clean, p, labels, clamp=False, want_logits=True):
         """Forward + CTC loss only.  ``clamp=False`` composes ``clean + p`` as the reference's evaluation does
         (evaluation.py:16); ``p=None`` evaluates the clean batch.  Returns dict(loss, logits)."""
+        clean, p = self._checked(clean, p)
         B, L = clean.shape
-        if L != self.length:
-            raise ValueError(f"Loaded perturbation length {L} != expected {self.length}")
         dev = self.device
         lab = None if labels is None else labels.to(device=dev, dtype=torch.int32).contiguous()
         logits = torch.empty(B, self.frames, self.arch.vocab_size, dtype=torch.float32, device=dev) if want_logits else None

@@ -4,9 +4,17 @@
 
 Data-parallel form: every rank holds the full universal perturbation and a shard of the
 utterances; because HF's CTC reduction is 'sum', the global gradient is the sum of the shard
-gradients, so ONE all-reduce (RCCL over xGMI via torch.distributed's "nccl" backend) of the packed
-vector [grad(L) | loss, sum clean^2, TV(clean), 0...] per step suffices; every rank then applies the
-identical sign step and projection, so replicas stay bit-identical without a broadcast.
+gradients, so ONE all-reduce (RCCL over xGMI via torch.distributed's "nccl" backend) per step of the packed
+f32 vector
+
+    [ grad (L) | loss, sum clean^2, TV(clean), wer_errors, wer_ref_words, 0, 0, 0 ]
+
+suffices; every rank then applies the identical sign step and projection, so replicas stay bit-identical
+without a broadcast.  ``sum clean^2`` / ``TV(clean)`` are there because project_snr / project_tv use
+whole-GLOBAL-batch statistics (projections.py:11-35, 56-66); the SNR target norm also uses the global
+``clean.numel()``, which is ``L * sum of the ranks' batch sizes`` — agreed on by one small collective whenever the
+local batch size changes (a short last batch), never per step.  The WER counters are the host-side bookkeeping of
+the PREVIOUS step (train.py:149-153 runs one step behind the GPU), reduced with the same buffer.
 """
 from __future__ import annotations
 
@@ -16,6 +24,7 @@ from .. import _lib, runtime
 
 FREQ_NORMS = ("fletcher_munson", "min_max_freqs", "max_phon")
 N_STATS = 8
+ST_LOSS, ST_SQ, ST_TV, ST_WER_ERR, ST_WER_REF = 0, 1, 2, 3, 4
 
 
 class PgdStepper:
@@ -37,45 +46,88 @@ class PgdStepper:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(group)
+        self.need_clean_stats = self.world > 1 and any(n in ("snr", "tv") for n in self.norms)
         self._prm = []
         for n in self.norms:
             a = type("A", (), dict(vars(args)))()
             a.norm_type = n
             self._prm.append(runtime.params_of(a))
+        self._wer_ring = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(4)] if self.world > 1 else None
+        self._wer_i = 0
+        self._wer_next = (0.0, 0.0)
+        self._shard_B = None           # local batch size the global element count below was agreed for
+        self._global_numel = None
 
-    def step(self, p: torch.Tensor, clean: torch.Tensor, labels: torch.Tensor, want_logits=True, logits_out=None):
-        """In place on ``p`` (1, L).  Returns dict(loss: 0-d device tensor, summed over ALL ranks, logits)."""
-        L = self.L
+    # ---- bookkeeping carried by the packed vector -------------------------------------------------------------
+    def set_wer_counts(self, errors: float, ref_words: float):
+        """Host-side WER counters of the PREVIOUS step (train.py:149-153): the next ``step`` writes them behind the
+        gradient, so its all-reduce sums them over ranks; read the global sums from ``stats[3:5]`` afterwards."""
+        self._wer_next = (float(errors), float(ref_words))
+
+    def _push_wer(self):
+        """This rank's WER counters of the previous step go behind the gradient (pinned ring: the copy is asynchronous,
+        so a slot must stay untouched until the GPU has consumed it)."""
+        if self.world == 1:
+            return
+        h = self._wer_ring[self._wer_i & 3]
+        self._wer_i += 1
+        h[0], h[1] = self._wer_next
+        self._wer_next = (0.0, 0.0)
+        self.stats[ST_WER_ERR:ST_WER_REF + 1].copy_(h, non_blocking=True)
+
+    def _sync_shards(self, B: int):
+        """Collective, only when the local batch size changes: global clean.numel() = L * sum_r B_r."""
+        t = torch.tensor([float(B)], dtype=torch.float64, device=self.dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        self._global_numel = float(t.item()) * self.L
+        self._shard_B = B
+
+    # ---- the two halves of a step (everything before / after the collective) ----------------------------------
+    def _pre(self, p, clean, labels, want_logits=True, logits_out=None):
         B = clean.shape[0]
-        lib = _lib.lib()
         out = {"grad": self.grad, "stats": self.stats}
         if logits_out is not None:
             out["logits"] = logits_out
         r = self.model.fwd_bwd(clean, p, labels, self.direction, want_grad=True, want_logits=want_logits, out=out)
-        need_clean_stats = self.world > 1 and any(n in ("snr", "tv") for n in self.norms)
-        st = _lib.stream_ptr()
+        if self.need_clean_stats:
+            with torch.cuda.device(self.dev):
+                _lib.check(_lib.lib().paa_batch_stats(self.proj.h, _lib.ptr(clean), B, self.L,
+                                                      _lib.ptr(self.stats[ST_SQ:ST_TV + 1]), _lib.stream_ptr()))
+        return r
+
+    def _post(self, p, clean):
+        lib, L, B = _lib.lib(), self.L, clean.shape[0]
         with torch.cuda.device(self.dev):
-            if need_clean_stats:
-                _lib.check(lib.paa_batch_stats(self.proj.h, _lib.ptr(clean), B, L, _lib.ptr(self.stats[1:3]), st))
-            if self.world > 1:
-                torch.distributed.all_reduce(self.packed, op=torch.distributed.ReduceOp.SUM, group=self.group)
             st = _lib.stream_ptr()
             _lib.check(lib.paa_sign_step(_lib.ptr(p), _lib.ptr(self.grad), float(self.args.lr), L, st))   # train.py:160-161
             for n, prm in zip(self.norms, self._prm):                                                   # train.py:162
-                if need_clean_stats and n in ("snr", "tv"):
-                    _lib.check(lib.paa_project_ext(self.proj.h, prm, _lib.ptr(p), 1, _lib.ptr(self.stats[1:3]),
-                                                   float(B * self.world * L), L, st))
+                if self.need_clean_stats and n in ("snr", "tv"):
+                    _lib.check(lib.paa_project_ext(self.proj.h, prm, _lib.ptr(p), 1, _lib.ptr(self.stats[ST_SQ:ST_TV + 1]),
+                                                   self._global_numel, L, st))
                 else:
                     _lib.check(lib.paa_project(self.proj.h, prm, _lib.ptr(p), 1, _lib.ptr(clean), B, L, st))
-        r["loss"] = self.stats[0]
+
+    def step(self, p: torch.Tensor, clean: torch.Tensor, labels: torch.Tensor, want_logits=True, logits_out=None):
+        """In place on ``p`` (1, L).  Returns dict(loss: 0-d device tensor, summed over ALL ranks, logits)."""
+        p = runtime.as_f32_cuda(p, "p")
+        clean = runtime.as_f32_cuda(clean, "clean_audio")
+        if p.numel() != self.L or clean.shape[-1] != self.L:
+            raise ValueError(f"Loaded perturbation length {p.numel()} / clip length {clean.shape[-1]} != expected {self.L}")
+        if self.need_clean_stats and clean.shape[0] != self._shard_B:
+            self._sync_shards(clean.shape[0])
+        self._push_wer()
+        r = self._pre(p, clean, labels, want_logits, logits_out)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.packed, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        self._post(p, clean)
+        r["loss"] = self.stats[ST_LOSS]
         return r
 
     def capture(self, p, clean, labels, logits_out=None):
-        """Capture one step on fixed buffers into a hipGraph (the launch sequence allocates nothing and never
+        """Capture one step on fixed buffers into hipGraphs (the launch sequence allocates nothing and never
         synchronises, so it is capturable as is).  Returns (graph, result dict); ``graph.replay()`` re-runs the step
-        in place on ``p`` with whatever ``clean`` / ``labels`` currently hold.  Single-rank only."""
-        if self.world > 1:
-            raise RuntimeError("graph capture of the data-parallel step is not enabled")
+        in place on ``p`` with whatever ``clean`` / ``labels`` currently hold.  With several ranks the halves before
+        and after the collective are two graphs and the all-reduce runs between their replays."""
         lab = labels.to(device=self.dev, dtype=torch.int32).contiguous()
         if logits_out is None:
             logits_out = torch.empty(clean.shape[0], self.model.frames, self.model.arch.vocab_size, device=self.dev)
@@ -84,7 +136,29 @@ class PgdStepper:
         with torch.cuda.stream(s):                       # warm-up on the side stream, as torch's capture rules require
             self.step(p, clean, lab, logits_out=logits_out)
         torch.cuda.current_stream(self.dev).wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            r = self.step(p, clean, lab, logits_out=logits_out)
-        return g, r
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                r = self.step(p, clean, lab, logits_out=logits_out)
+            return g, r
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            r = self._pre(p, clean, lab, True, logits_out)
+        torch.distributed.all_reduce(self.packed, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        with torch.cuda.graph(g2):
+            self._post(p, clean)
+        r["loss"] = self.stats[ST_LOSS]
+        return _SplitGraph(self, g1, g2), r
+
+
+class _SplitGraph:
+    """replay() = pre-collective graph, all-reduce of the packed vector, post-collective graph."""
+
+    def __init__(self, stepper, g1, g2):
+        self.stepper, self.g1, self.g2 = stepper, g1, g2
+
+    def replay(self):
+        self.stepper._push_wer()
+        self.g1.replay()
+        torch.distributed.all_reduce(self.stepper.packed, op=torch.distributed.ReduceOp.SUM, group=self.stepper.group)
+        self.g2.replay()

@@ -77,13 +77,15 @@ def train_epoch(args, train_data_loader, p: torch.Tensor, model, epoch: int, pro
         model._stepper = stepper
     for clean_audio, target_texts in train_data_loader:
         t0 = time.perf_counter()
-        clean_audio = clean_audio.to(args.device, non_blocking=True)                # train.py:129
+        clean_audio = clean_audio.to(args.device, torch.float32, non_blocking=True).contiguous()   # train.py:129
         labels = loss_helpers.make_labels(target_texts, processor, args, len(clean_audio))
         if args.optimizer_type == "pgd":
             if isinstance(p, torch.nn.Parameter) or p.requires_grad:
                 p = p.detach()
             r = stepper.step(p, clean_audio, labels)
         else:
+            if p.dtype != torch.float32 or not p.is_cuda:
+                raise TypeError(f"the Adam branch needs a float32 perturbation on the GPU, got {p.dtype} on {p.device}")
             r = model.fwd_bwd(clean_audio, p.data, labels, stepper.direction)
             optimizer.zero_grad(set_to_none=True)
             p.grad = -r["grad"].view_as(p)          # gradient of (-direction * loss), train.py:170

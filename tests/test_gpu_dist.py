@@ -83,3 +83,31 @@ def test_two_ranks_equal_one(norm):
     scale = np.abs(p.cpu().numpy()).max()
     print(f"{norm}: DP vs single max diff {diff.max() / scale:.2e}; fraction differing {(diff > 1e-6 * scale).mean():.2e}")
     assert (diff > 1e-5 * scale).mean() < 5e-3          # only where a gradient sign is numerically undecided
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its two ranks itself (fresh children, before any GPU
+    call) and prints rank 0's JSON line; here both ranks share the one GPU of the test box over gloo, which rehearses
+    the launch path, the packed all-reduce (grad + loss + clean statistics + WER counters) and the weak-scaling
+    accounting.  RCCL itself needs one device per rank and is not exercised by this test."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PAA_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+                        "--seconds", "1", "--arch", "tiny", "--label_tokens", "10", "--no_cpu_baseline", "--no_fft_bench"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    assert d["value"] > 0 and np.isfinite(d["config"]["last_loss"]) and "bf16" in d
+    assert "last_wer_all_ranks" in d["config"]
+    # a failing rank must fail the whole run, loudly
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                         "--seconds", "0.001", "--arch", "tiny", "--no_cpu_baseline", "--no_fft_bench"],
+                        env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode != 0 and "rank" in r2.stderr

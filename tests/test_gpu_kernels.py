@@ -248,7 +248,7 @@ def test_softmax_fwd_bwd():
     assert float(sd[:, cols:].abs().max()) == 0 and float(dpd[:, cols:].abs().max()) == 0
 
 
-# label capacities: 2 S_max + 1 <= 1024 -> wave-synchronous probability-domain kernels (1, 2, 6, 16 states per lane);
+# label capacities: 2 S_max + 1 <= 1024 -> wave-synchronous log-domain kernels (1, 2, 6, 16 states per lane);
 # (700, 600): the log-domain kernel for larger capacities; (60, 30, [.., 40->infeasible]) is covered by lens > T below
 @pytest.mark.parametrize("T,S_max,lens", [(24, 6, [5, 6, 3, 0]), (499, 150, [150, 120, 1, 77]), (60, 30, [30, 29, 30, 2]),
                                           (80, 40, [40, 1, 33, 40]), (499, 499, [300, 150, 499, 250]), (700, 600, [600, 150, 20, 333])])
@@ -282,6 +282,44 @@ def test_ctc(T, S_max, lens):
     e1 = rel_err(out_nll.cpu()[fin], nll.detach()[fin])
     e2 = rel_err(dl.cpu()[fin], lr.grad[fin])
     print(f"ctc T={T}: nll {e1:.2e} grad {e2:.2e}")
+    assert e1 < 2e-6 and e2 < 1e-5
+
+
+# Peaked posteriors: a trained CTC model puts the blank far above everything else, and the reference's labels
+# are <unk> / | strings, so the target path sits thousands of nats below the all-blank path at every frame.
+# A probability-domain recursion rescaled by the row maximum underflows there (loss inf, gradient NaN); the log-domain
+# recursion must return the float64 value.  Cases: untargeted-size labels (S=150), the default targeted string
+# "delete" x 5 (S=34: all <unk>=3 and |=4), near-uniform control, and 30 s clips (T=1499, lp table read from global).
+@pytest.mark.parametrize("T,S,blank_up,unk_down", [(499, 150, 8.0, -15.0), (499, 34, 10.0, -20.0), (499, 150, 3.0, -3.0),
+                                                    (1499, 450, 12.0, -25.0), (499, 150, 40.0, -40.0)])
+def test_ctc_peaked_logits(T, S, blank_up, unk_down):
+    torch.manual_seed(4)
+    B, V = 3, 32
+    logits = torch.randn(B, T, V) * 0.5
+    logits[:, :, 0] += blank_up
+    logits[:, :, 3] += unk_down
+    labels = torch.full((B, S), -100, dtype=torch.long)
+    for b in range(B):
+        n = S - 7 * b
+        labels[b, :n] = torch.tensor([4 if (i % 6) == 5 else 3 for i in range(n)])      # "uuuuu|uuuuu|..." (F6)
+    lr = logits.double().clone().requires_grad_(True)
+    lp = F.log_softmax(lr, -1).transpose(0, 1)
+    mask = labels >= 0
+    nll = F.ctc_loss(lp, labels.masked_select(mask), torch.full((B,), T), mask.sum(-1), blank=0, reduction="none",
+                     zero_infinity=False)
+    nll.sum().backward()
+    assert bool(torch.isfinite(nll).all())
+    lg, lab = logits.cuda(), labels.to(torch.int32).cuda()
+    out_nll = torch.empty(B, device="cuda"); dl = torch.empty_like(lg)
+    L = _lib.lib()
+    work = torch.empty(L.paa_ctc_work_floats(B, T, V, S), device="cuda")
+    _lib.check(L.paa_ctc(_lib.ptr(lg), _lib.ptr(lab), B, T, V, S, 0, 1.0, _lib.ptr(out_nll), _lib.ptr(dl), _lib.ptr(work), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    print("ctc peaked nll", out_nll.cpu().tolist(), nll.tolist())
+    assert bool(torch.isfinite(out_nll).all()) and bool(torch.isfinite(dl).all())
+    e1 = rel_err(out_nll.cpu(), nll.detach())
+    e2 = rel_err(dl.cpu(), lr.grad)
+    print(f"ctc peaked T={T} S={S}: nll {e1:.2e} grad {e2:.2e}")
     assert e1 < 2e-6 and e2 < 1e-5
 
 

@@ -96,3 +96,26 @@ def test_batched_rows_and_errors():
     p = torch.from_numpy(synth.perturbation(160000) * np.float32(1e-2)).cuda()
     y = fourier_transforms.compute_istft(fourier_transforms.compute_stft(p, a2), a2)
     assert float((y - p[:, : y.shape[1]]).abs().max()) < 2e-8 * 100
+
+
+def test_compose_clamp_clamp_box_and_argmax():
+    """The small boundary entries: train.py:136 compose + clamp, projections.py:37-39 with an asymmetric box,
+    loss_helpers.py:26 argmax — each against the torch expression the reference evaluates."""
+    from paa_amd import _lib
+    from paa_amd.core import loss_helpers
+    lib = _lib.lib()
+    B, L = 3, 5000
+    x = torch.from_numpy(synth.clean_audio(B, L)).cuda() * 12.0          # pushes samples outside [-1, 1]
+    p = torch.from_numpy(synth.perturbation(L) * np.float32(0.3)).cuda()
+    out = torch.empty_like(x)
+    _lib.check(lib.paa_compose_clamp(_lib.ptr(x), _lib.ptr(p), _lib.ptr(out), B, L, _lib.stream_ptr()))
+    ref = (x + p).clamp_(-1.0, 1.0)
+    assert torch.equal(out, ref) and float((ref.abs() == 1).float().mean()) > 0.01
+    q = projections.project_linf(p, -0.05, 0.2)
+    assert torch.equal(q, torch.clamp(p, -0.05, 0.2)) and float(q.min()) == pytest.approx(-0.05) and float(q.max()) == pytest.approx(0.2)
+    assert torch.equal(projections.project_linf(p, 0.3, 0.1), torch.clamp(p, 0.3, 0.1))     # min > max: everything becomes max
+    torch.manual_seed(0)
+    lg = torch.randn(4, 499, 32, device="cuda")
+    lg[0, 5, 7] = lg[0, 5, 9] = 50.0                                      # a tie: the first maximum wins
+    ids = loss_helpers.argmax_ids(lg)
+    assert ids.dtype == torch.int16 and torch.equal(ids.long(), torch.argmax(lg, dim=-1)) and int(ids[0, 5]) == 7

@@ -1,26 +1,35 @@
 """Latency / bandwidth of the projection path: every norm at the reference shape (1, L) — where it is
 launch-latency-bound — and in the batched mode (32, L), reported as algorithmic GB/s (8*rows*L bytes: read p + write p,
-plus 4*B*L for the clean-batch statistic of snr / tv) against the 8 TB/s HBM peak.  Run on the GPU box."""
+plus 4*B*L for the clean-batch statistic of snr / tv) against the 8 TB/s HBM peak.  Run on the GPU box:
+
+    python tools/proj_bench.py                 # every norm, JSON list on the last line
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/proj_bench.py --spectral   # the three FFT norms only
+
+`roofline_block()` is what bench.py embeds as `roofline_fft`.
+"""
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 
 from paa_amd import _lib, runtime, synth
 from paa_amd.training_utils import build, parser
 
+SPECTRAL = ("min_max_freqs", "fletcher_munson", "max_phon")
+ALL = ("l2", "linf", "snr", "tv") + SPECTRAL
+HBM_PEAK_GBPS = 8000.0
 
-def main(L=160000, B=32, iters=50):
+
+def measure(norms=ALL, rows_list=(1, 32), L=160000, B=32, iters=50, dev="cuda", verbose=True):
     lib = _lib.lib()
     out = []
-    clean = torch.from_numpy(synth.clean_audio(B, L)).cuda()
-    for norm in ("l2", "linf", "snr", "tv", "min_max_freqs", "fletcher_munson", "max_phon"):
-        args = parser.create_arg_parser().parse_args(["--norm_type", norm, "--snr_db", "40", "--device", "cuda"])
-        for rows in (1, B):
-            p = (torch.randn(rows, L, device="cuda") * 1e-2).contiguous()
+    clean = torch.from_numpy(synth.clean_audio(B, L)).to(dev)
+    for norm in norms:
+        args = parser.create_arg_parser().parse_args(["--norm_type", norm, "--snr_db", "40", "--device", str(dev)])
+        for rows in rows_list:
+            p = (torch.randn(rows, L, device=dev) * 1e-2).contiguous()
             pr = runtime.get_proj(args, p.device, rows, L)
             pr.set_spl_thresh(build.init_phon_threshold_tensor(args))
             prm = runtime.params_of(args)
@@ -40,10 +49,31 @@ def main(L=160000, B=32, iters=50):
             us = e0.elapsed_time(e1) * 1e3 / iters
             nbytes = 8 * rows * L + (4 * B * L if norm in ("snr", "tv") else 0)
             out.append(dict(norm=norm, rows=rows, us=round(us, 2), algorithmic_MB=round(nbytes / 1e6, 2),
-                            GBps=round(nbytes / us / 1e3, 1), frac_of_8TBps=round(nbytes / us / 1e3 / 8000, 4)))
-            print(out[-1], flush=True)
-    print(json.dumps(out))
+                            GBps=round(nbytes / us / 1e3, 1), frac_of_8TBps=round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)))
+            if verbose:
+                print(out[-1], file=sys.stderr, flush=True)
+    return out
+
+
+def roofline_block(dev="cuda", L=160000, B=32):
+    """FFT / projection path roofline for the bench line: the fused STFT -> per-bin projection -> iSTFT kernel of each
+    spectral norm in the batched (32, L) mode (HBM-bound by its algorithmic bytes 8*rows*L) and its latency at the
+    reference shape (1, L).  Timed with HIP events on the launch stream, 50 calls each."""
+    rows = measure(SPECTRAL, (1, B), L, B, 50, dev, verbose=False)
+    blk = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernel": "k_spec_fused<OP> (STFT -> per-bin op -> iSTFT + overlap-add, one launch)",
+           "algorithmic_bytes": 8 * B * L, "shape": [B, L], "norms": {}}
+    for r in rows:
+        d = blk["norms"].setdefault(r["norm"], {})
+        if r["rows"] == B:
+            d.update(achieved=r["GBps"], frac=r["frac_of_8TBps"], us=r["us"])
+        else:
+            d["latency_us_1xL"] = r["us"]
+    worst = min(blk["norms"].values(), key=lambda d: d["achieved"])
+    blk["achieved"], blk["frac"] = worst["achieved"], worst["frac"]
+    blk["traffic"] = None
+    return blk
 
 
 if __name__ == "__main__":
-    main()
+    res = measure(SPECTRAL if "--spectral" in sys.argv else ALL)
+    print(json.dumps(res))
