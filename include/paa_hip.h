@@ -152,6 +152,10 @@ int paa_model_layout(const paa_model* m, int i);  /* padded rows of conv layer i
  * See csrc/gemm.h for the descriptor; exported so tests can check each variant against the oracle. */
 struct paa_gemm_desc;
 paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
+/* Test / measurement aid: kernel selection of paa_gemm for the large regular products.  0 = automatic (default),
+ * 1 = register-staged kernels only, 2.. = force one LDS-DMA ring configuration wherever its shape constraints hold
+ * (csrc/gemm_ring.hip).  Results are bit-identical across configurations (same K order); tests assert that. */
+void paa_gemm_config(int ring_mode);
 /* Measurement aid (bench.py roofline leg): HIP-event timing of every GEMM launch on its own stream.
  * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[64][3] =
  * {launches, total ms, total algorithmic FLOP (2*M*N*K*batch)} per kernel variant

@@ -81,6 +81,7 @@ _SIGS = {
     "paa_model_debug_read": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int]),
     "paa_model_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "paa_gemm": (C.c_int, [C.POINTER(PaaGemmDesc), C.c_void_p]),
+    "paa_gemm_config": (None, [C.c_int]),
     "paa_prof_enable": (C.c_int, [C.c_int]),
     "paa_prof_read": (C.c_int, [C.c_void_p]),
     "paa_prof_pause": (C.c_int, [C.c_int]),

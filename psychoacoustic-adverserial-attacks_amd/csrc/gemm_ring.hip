@@ -1,0 +1,278 @@
+// LDS-DMA ring GEMM kernels for gfx950 (see gemm.h for the contract, gemm_dev.h for the shared epilogues).
+#include <algorithm>
+
+#include "gemm_dev.h"
+
+namespace paa {
+
+// ---- LDS-DMA ring kernel: 256 x (256|128) tiles, one 8-wave workgroup per CU ------------------------------------------
+// The large products of the step (conv stack, FFN, QKV) at the operand cost per FLOP of a 256 x 256 bf16 tile (or a
+// 256 x 128 split-bf16 tile: three MFMAs per operand pair make it equally dense).  Operand K slabs go global -> LDS by
+// global_load_lds_dwordx4 (no staging registers, no ds_write) into a ring of NST stages; the load cursor runs NST - 1
+// stages ahead of the MFMAs over the flat (output tile, K slab) sequence of this persistent workgroup, so tile
+// boundaries do not drain it; ONE workgroup barrier per stage, and a COUNTED s_waitcnt vmcnt in front of it keeps the
+// younger stages in flight across the barrier (a stage has NST - 2 whole compute stages to land; the 2-stage form of
+// round 1 waited vmcnt(0) every K tile and exposed the DMA's issue-to-landed time).  The DMA writes LDS lane-linearly, so
+// the bank-conflict swizzle lives on the SOURCE side: slot p of LDS row r receives global chunk p ^ f(r), and the
+// fragment reads apply the same XOR (f = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows: every
+// ds_read_b128 lane group then covers all 64 banks).  B rows are permuted inside each 64-row group exactly as
+// store_bf<PERM> does, for the vector epilogue.  Stage layout: A_hi rows | B_hi rows [| A_lo rows | B_lo rows].
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// AHEAD: the barrier of iteration `it` certifies stage it + 1 (not just `it`), so the first fragments of the NEXT stage can
+// be read from LDS under the last MFMAs of the current one and the MFMAs after a barrier start at once instead of
+// waiting out an LDS round trip that all eight lock-stepped waves would sit through together; costs one stage of
+// prefetch distance (NST - 2 stages in flight instead of NST - 1).
+template <int BM, int BN, int BK, int PREC, int NST, int WR, int WC, bool AHEAD, int WPS = 2>
+__global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
+    constexpr int NW = WR * WC;
+    constexpr int NPL = PREC ? 2 : 1;
+    constexpr int RB = BK * 2;                 // bytes per LDS row (one plane)
+    constexpr int CPR = RB / 16;               // 16-byte chunks per row
+    constexpr int RPI = 1024 / RB;             // rows per DMA wave-instruction
+    constexpr int RBR = 256 / RB;              // rows per 256-byte bank row
+    constexpr int PROWS = BM + BN;             // rows of one plane
+    constexpr int ROWS = PROWS * NPL;
+    constexpr int STAGE = ROWS * RB;
+    constexpr int GPW = ROWS / RPI / NW;       // DMA wave-instructions per wave per stage
+    constexpr int MI = BM / WR / 32, NJ = BN / WC / 32, KS = BK / 16;
+    constexpr int D = NST - 1;                 // stages in flight ahead of the MFMAs
+    static_assert(NJ == 2, "vector epilogue: 64 columns per wave");
+    static_assert(ROWS % (RPI * NW) == 0 && BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "a DMA round must not straddle operands");
+    static_assert(NST * STAGE <= 160 * 1024 && D >= 1 && D <= 3 && D * GPW < 64, "ring does not fit");
+    static_assert(!AHEAD || D >= 2, "certifying one stage ahead needs two stages of lookahead");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+    const paa_gemm_desc& d = g.d;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int total = nwg * d.batch;
+    const int nk = d.K / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    struct Tile { int m0, n0, z1, z2; };
+    auto decode = [&](int t) {
+        Tile c;
+        const int z = t / nwg, orig = t - z * nwg;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+        c.m0 = tm * BM; c.n0 = tn * BN;
+        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
+        return c;
+    };
+
+    // ---- load cursor: (tile lt, K slab lk) is the next stage to request --------------------------------------------
+    int lt = blockIdx.x, lk = 0;
+    if (lt >= total) return;
+    const unsigned short* src[GPW];
+    auto set_src = [&](int t) {
+        const Tile c = decode(t);
+        const int64_t aoff = c.z1 * d.a_s1 + c.z2 * d.a_s2, boff = c.z1 * d.b_s1 + c.z2 * d.b_s2;
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const int r = (i * NW + wave) * RPI + lane / CPR;             // ring row of this lane's chunk
+            const int pl = (i * NW * RPI) / PROWS;                         // plane and operand are compile-time per i
+            const int rr = r - pl * PROWS;
+            const int ch = (lane % CPR) ^ ((r / RBR) & (CPR - 1));        // global chunk that lands in slot lane % CPR
+            if ((i * NW * RPI) % PROWS < BM) {
+                const unsigned short* A = reinterpret_cast<const unsigned short*>(pl ? d.A_lo : (const void*)d.A) + aoff;
+                src[i] = A + (int64_t)min(c.m0 + rr, d.M - 1) * d.lda + ch * 8;
+            } else {
+                const unsigned short* B = reinterpret_cast<const unsigned short*>(pl ? d.B_lo : (const void*)d.B) + boff;
+                const int p = rr - BM;
+                const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);
+                src[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
+            }
+        }
+    };
+    auto issue = [&](int slot) {
+        unsigned char* st = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < GPW; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lk * BK), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
+        if (++lk == nk) {
+            lk = 0;
+            lt += gridDim.x;
+            if (lt < total) set_src(lt);
+        }
+    };
+    set_src(lt);
+    int pend = 0, islot = 0;                   // stages requested and not yet consumed; next slot to fill
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (lt < total) { issue(islot); islot = islot + 1 == NST ? 0 : islot + 1; ++pend; }
+
+    // fragment addressing: row base + swizzled 16-byte chunk of the k slice
+    const int sw = (lr / RBR) & (CPR - 1);
+    int offk[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
+    const int arow = (wr * (BM / WR) + lr) * RB, brow = (BM + wc * (BN / WC) + lr) * RB;
+    constexpr int LO = PROWS * RB;             // hi -> lo plane distance inside a stage
+
+    int cslot = 0;                             // slot of the stage the MFMAs consume next
+    constexpr int NM = NJ * (PREC ? 3 : 1);
+    bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
+    auto first_frags = [&](int slot) {         // the fragments the first MFMA group of a stage needs -> the "next" registers
+        const unsigned char* sa = smem + slot * STAGE + arow;
+        const unsigned char* sb = smem + slot * STAGE + brow;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[0]);
+            if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + LO + j * 32 * RB + offk[0]);
+        }
+        ahn = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
+        if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + LO + offk[0]);
+    };
+    if constexpr (AHEAD) {                     // stages 0 and 1 landed everywhere; stage 0's first fragments in registers
+        if (pend >= 3) wait_vmcnt<(D >= 3 ? 1 : 0) * GPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        first_frags(0);
+    }
+    bool first_it = true;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const Tile cur = decode(t);
+        f32x16 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (AHEAD) {
+                // stage `cslot` was certified by the previous barrier; this one certifies the stage after it
+                if (!first_it) {
+                    if (pend >= 3) wait_vmcnt<(D >= 3 ? 1 : 0) * GPW>(); else wait_vmcnt<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                first_it = false;
+            } else {
+                // my pieces of the oldest pending stage have landed; the younger ones stay in flight across the barrier
+                if (pend >= 3) wait_vmcnt<(D >= 3 ? 2 : 0) * GPW>();
+                else if (pend == 2) wait_vmcnt<(D >= 2 ? 1 : 0) * GPW>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();      // everyone's have; everyone is done reading the slot refilled next
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lt < total) { issue(islot); islot = islot + 1 == NST ? 0 : islot + 1; } else --pend;
+            const unsigned char* sa = smem + cslot * STAGE + arow;
+            const unsigned char* sb = smem + cslot * STAGE + brow;
+            cslot = cslot + 1 == NST ? 0 : cslot + 1;
+            if constexpr (AHEAD) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { bh[j] = bhn[j]; bl[j] = bln[j]; }
+                ah = ahn; al = aln;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[0]);
+                    if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sb + LO + j * 32 * RB + offk[0]);
+                    bhn[j] = bh[j]; bln[j] = bl[j];
+                }
+                ah = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
+                if (PREC) al = *reinterpret_cast<const bf16x8*>(sa + LO + offk[0]);
+                ahn = ah; aln = al;
+                __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
+                    if (nks < KS) {
+                        ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 32 * RB + offk[nks < KS ? nks : 0]);
+                        if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + LO + ni * 32 * RB + offk[nks < KS ? nks : 0]);
+                        if (ni == 0) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) {
+                                bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[nks < KS ? nks : 0]);
+                                if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + LO + j * 32 * RB + offk[nks < KS ? nks : 0]);
+                            }
+                        }
+                    } else if constexpr (AHEAD) {
+                        first_frags(cslot);            // next stage (certified by this iteration's barrier); garbage after the last one
+                    }
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (PREC) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    if (nks < KS) {
+                        if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+                    } else if constexpr (AHEAD) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+                    if (nks < KS) {
+                        ah = ahn; al = aln;
+                        if (ni == 0) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) { bh[j] = bhn[j]; bl[j] = bln[j]; }
+                        }
+                    }
+                }
+        }
+        epilogue_vec<MI, PREC == 0>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
+    }
+}
+
+// resident workgroups of a kernel on this device (CUs x occupancy)
+template <typename K>
+static int ring_resident_blocks(K kernel, int threads) {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) return 0;
+    return cus * per;
+}
+
+template <int BM, int BN, int BK, int PREC, int NST, int WR, int WC, bool AHEAD, int WPS = 2>
+static void launch_ring(const GemmArgs& g, hipStream_t st) {
+    static const int resident = ring_resident_blocks(k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS>, WR * WC * 64);
+    const int total = g.tiles_m * g.tiles_n * g.d.batch;
+    const int blocks = resident > 0 ? std::min(total, resident) : total;
+    hipLaunchKernelGGL((k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
+}
+
+void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
+    switch (cfg) {
+        case 2: launch_ring<256, 256, 64, 0, 2, 2, 4, false>(g, st); break;     // bf16, 2 stages of 64 KB (the round-1 structure)
+        case 3: launch_ring<256, 256, 32, 0, 4, 2, 4, false>(g, st); break;     // bf16, 4 stages of 32 KB, 3 in flight
+        case 4: launch_ring<256, 128, 32, 1, 3, 4, 2, false>(g, st); break;     // split, 3 stages of 48 KB, 2 in flight
+        case 5: launch_ring<256, 256, 32, 0, 4, 2, 4, true>(g, st); break;      // bf16, 4 stages, certified one ahead
+        case 6: launch_ring<256, 128, 32, 1, 3, 4, 2, true>(g, st); break;      // split, 3 stages, certified one ahead
+        case 7: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2>(g, st); break;  // split, 192-row tiles, 2 x 40 KB, two workgroups per CU
+        default: break;
+    }
+}
+
+int ring_tile_rows(int cfg) { return cfg == 7 ? 192 : 256; }
+int ring_tile_cols(int cfg) { return (cfg == 4 || cfg == 6 || cfg == 7) ? 128 : 256; }
+bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
+    if (cfg < 2 || cfg > 7) return false;
+    const bool split = cfg == 4 || cfg == 6 || cfg == 7;
+    if (split != (d.precision != 0)) return false;
+    const int bk = cfg == 2 ? 64 : 32;
+    return d.K % bk == 0 && d.K >= 4 * bk;
+}
+
+}  // namespace paa

@@ -160,6 +160,7 @@ def _bf_case(name, d, shapes, prec, seed=0, offs=None, x16=False, gate=False):
     assert eb < (3e-5 if prec else 5e-3), name
     # a kept gelu'(v) inherits the product's error scaled by max|v| / max|gelu'| (~30x here)
     assert ep < (5e-3 if x16 else (3e-4 if gate else (3e-5 if prec else 5e-6))), name
+    return {k: bufs[k].clone() for k in ("C", "Cb", "Cb_lo", "C_pre") if k in bufs}
 
 
 @pytest.mark.parametrize("prec", [0, 1])
@@ -206,6 +207,31 @@ def test_gemm_bf16_operands(prec):
     _bf_case("small_gate_f32", dict(M=300, N=100, K=96, lda=96, ldb=96, ldc=100, act=1), dict(A=300 * 96, B=100 * 96, C=300 * 100, bias=100, C_pre=300 * 100), prec, gate=True)
     _bf_case("dgrad_aux16", dict(M=Mr, N=Ci, K=2 * Co, lda=Co, ldb=2 * Co, ldc=2 * Ci, act=2, ld_aux=2 * Ci),
              dict(A=(Mr + 8) * Co, B=Ci * 2 * Co, C=Mr * 2 * Ci, aux=Mr * 2 * Ci), prec, offs=dict(A=7 * Co, C=Ci, aux=Ci), x16=True)
+
+
+@pytest.mark.parametrize("prec,cfg", [(0, 2), (0, 3), (1, 4)])
+def test_gemm_ring_configurations(prec, cfg):
+    """LDS-DMA ring kernels (csrc/gemm_ring.hip) forced through paa_gemm_config: vs the numpy statement of the descriptor
+    and BIT-identical to the register-staged kernel (cfg 1) on the same buffers — M / N edges inside the last tiles, a
+    conv-style overlapping A view with a row mask, every epilogue stream of the vector epilogue."""
+    L = _lib.lib()
+    try:
+        for name, d, shapes, kw in [
+            ("ring_gelu", dict(M=2200, N=640, K=320, lda=320, ldb=320, ldc=640, alpha=0.5, act=1),
+             dict(A=2200 * 320, B=640 * 320, C=2200 * 640, bias=640, C_pre=2200 * 640), dict(x16=prec == 0, gate=prec == 0)),
+            ("ring_resid", dict(M=2304, N=768, K=768, lda=768, ldb=768, ldc=768, ld_res=768),
+             dict(A=2304 * 768, B=768 * 768, C=2304 * 768, residual=2304 * 768), {}),
+            ("ring_convview", dict(M=4000, N=512, K=384, lda=256, ldb=384, ldc=512, row_period=500, row_valid=499, act=2, ld_aux=512),
+             dict(A=(2 * 4000 + 8) * 128, B=512 * 384, C=4000 * 512, aux=4000 * 512), dict(x16=prec == 0, gate=prec == 0)),
+        ]:
+            outs = {}
+            for c in (1, cfg):
+                L.paa_gemm_config(c)
+                outs[c] = _bf_case(f"{name}/cfg{c}", d, shapes, prec, seed=7, **kw)
+            for k in outs[1]:
+                assert torch.equal(outs[1][k], outs[cfg][k]), (name, k, "ring result differs from the register-staged kernel")
+    finally:
+        L.paa_gemm_config(0)
 
 
 def test_layernorm_fwd_bwd():
