@@ -70,6 +70,22 @@ paa_status paa_proj_set_spl_thresh(paa_proj* h, const float* spl_thresh /* host,
 paa_status paa_project(paa_proj* h, const paa_params* prm, float* d_p, int rows_p,
                        const float* d_clean, int B, int L, void* stream);
 
+/* Out-of-place form of paa_project: reads d_src (rows_p, L), writes d_dst (rows_p, L); the two must not overlap.  This is
+ * how the reference's functions behave (they return a new tensor, projections.py:24,33,46) and it is the fast path of the
+ * frequency-domain norms: ONE fused launch (STFT -> per-bin op -> iSTFT + overlap-add; plus the scale launch for
+ * fletcher_munson), whereas the in-place form goes through the workspace and a copy-back launch. */
+paa_status paa_project_to(paa_proj* h, const paa_params* prm, const float* d_src, float* d_dst, int rows_p,
+                          const float* d_clean, int B, int L, void* stream);
+
+/* core/projections.py:68-80 project_min_max_freqs, :116-133 project_fm_norm, :138-159 project_phon_level applied to a
+ * spectrum the caller already holds (these reference functions take the complex (B, F, T) STFT tensor, train.py:52-59):
+ * d_S_in / d_S_out (B, T, F) complex64 interleaved, frame-major (the transposed view of the reference's layout);
+ * in place allowed.  prm->norm_type must be one of the three frequency-domain norms (else PAA_ERR_BAD_NORM). */
+paa_status paa_spectrum_project(paa_proj* h, const paa_params* prm, const float* d_S_in, float* d_S_out, int B, int T,
+                                void* stream);
+/* core/projections.py:83-113 compute_fm_weighted_norm_interp: d_out[0] = sqrt(sum |S|^2 * w(10 log10(|S|^2 + 1e-10), f_bin)) */
+paa_status paa_fm_weighted_norm(paa_proj* h, const float* d_S, int B, int T, float* d_out, void* stream);
+
 /* Data-parallel form: project_snr / project_tv use whole-batch statistics of the clean
  * audio, so ranks all-reduce [sum clean^2, TV(clean)] (paa_batch_stats on each shard) and pass the
  * global values plus the global element count here instead of the clean batch itself. */

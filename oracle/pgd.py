@@ -104,3 +104,29 @@ def pgd_step(sd, arch, args, clean, labels, p, spl_thresh=None):
         p_new = p.detach() + args.lr * grad.sign()                       # train.py:161
         p_new = P.perturbation_constraint(p_new, clean, args, spl_thresh)  # train.py:162
     return dict(loss=loss.detach(), logits=logits.detach(), grad=grad, p_new=p_new.detach())
+
+
+def train_epoch(sd, arch, args, loader, p, optimizer=None, spl_thresh=None):
+    """train.py:103-182 over a loader of (clean (B, L), texts): the PGD branch (:156-164) or the Adam branch (:165-175:
+    zero_grad, (-direction * loss).backward(), optimizer.step(), p.data = constraint(p.data)).  Returns
+    (p, mean of the per-batch sum-reduced CTC losses, mean of the per-batch WERs vs the ground truth)."""
+    direction = +1 if args.attack_mode == "untargeted" else -1
+    ctc, wers = [], []
+    for clean, texts in loader:
+        labels = make_labels(texts, args, len(clean))
+        if args.optimizer_type == "pgd":
+            r = pgd_step(sd, arch, args, clean, labels, p, spl_thresh)
+            p = r["p_new"]
+            loss, logits = r["loss"], r["logits"]
+        else:
+            optimizer.zero_grad(set_to_none=True)
+            perturbed = (clean + p).clamp(-1.0, 1.0)
+            loss, logits = W.forward(sd, arch, perturbed, labels)
+            (-direction * loss).backward()
+            optimizer.step()
+            with torch.no_grad():
+                p.data = P.perturbation_constraint(p.data, clean, args, spl_thresh)
+            loss, logits = loss.detach(), logits.detach()
+        ctc.append(float(loss))
+        wers.append(compute_wer(logits, texts))
+    return p, sum(ctc) / len(ctc), sum(wers) / len(wers)

@@ -60,6 +60,10 @@ _SIGS = {
     "paa_proj_set_spl_thresh": (C.c_int, [C.c_void_p, C.c_void_p]),
     "paa_project": (C.c_int, [C.c_void_p, C.POINTER(PaaParams), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                               C.c_void_p]),
+    "paa_project_to": (C.c_int, [C.c_void_p, C.POINTER(PaaParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "paa_spectrum_project": (C.c_int, [C.c_void_p, C.POINTER(PaaParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "paa_fm_weighted_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "paa_project_ext": (C.c_int, [C.c_void_p, C.POINTER(PaaParams), C.c_void_p, C.c_int, C.c_void_p, C.c_double,
                                   C.c_int, C.c_void_p]),
     "paa_batch_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "paa_common.h"
+#include "spec_kernels.h"
 
 namespace paa {
 
@@ -232,6 +233,36 @@ __global__ __launch_bounds__(RED_NT) void k_fm_finalize(const double* __restrict
     }
 }
 
+// Second launch of a fused spectral projection: dst = src * scale, the scale being the predicated FM factor computed from
+// the per-workgroup partial sums of the first launch (every block re-sums the few hundred partials: no third launch);
+// npart = 0: plain copy (min_max_freqs / max_phon, in-place form only).
+__global__ __launch_bounds__(RED_NT) void k_spec_finish(const float* __restrict__ src, float* __restrict__ dst, int64_t n,
+                                                      const double* __restrict__ part, int npart, float eps, float* __restrict__ scal) {
+    __shared__ double red[RED_NT / 64];
+    float scale = 1.f;
+    if (npart > 0) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < npart; i += RED_NT) s += part[i];
+        s = block_sum<double, RED_NT>(s, red);
+        const float norm = sqrtf((float)s);
+        scale = (norm <= eps) ? 1.f : eps / fmaxf(norm, 1e-8f);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && scal) { scal[0] = scale; scal[1] = norm; }
+    }
+    const int64_t n4 = n >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * RED_NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RED_NT) {
+            float4 v = s4[i];
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            d4[i] = v;
+        }
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * RED_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * RED_NT) dst[i] = src[i] * scale;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * RED_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * RED_NT) dst[i] = src[i] * scale;
+    }
+}
+
 // ---- time-domain reductions --------------------------------------------------------------------
 enum RedMode { RED_SQ = 0, RED_TV = 1 };
 
@@ -376,6 +407,13 @@ extern "C" paa_status paa_proj_create(paa_proj** out, int n_fft, int hop, int wi
         tw[m] = make_float2((float)cos(ang), (float)sin(ang));
         w[m] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)m / (double)n_fft));   // torch.hann_window (periodic)
     }
+    // torch.istft refuses windows whose overlap-added squared envelope touches zero (NOLA); so does this library
+    // (hop == n_fft with a Hann window would divide by zero in the overlap-add)
+    for (int r = 0; r < hop; ++r) {
+        double env = 0.0;
+        for (int n = r; n < n_fft; n += hop) env += (double)w[n] * (double)w[n];
+        if (env < 1e-11) { delete h; PAA_FAIL(PAA_ERR_ARG, "window overlap-add envelope is zero at offset %d (hop_length=%d, n_fft=%d): iSTFT undefined", r, hop, n_fft); }
+    }
     std::vector<float> fm(10 * F, 1.f), thr(F, 0.f);
     if (fm_table) for (int i = 0; i < 10 * F; ++i) fm[i] = (float)fm_table[i];
     const int Tmax = 1 + max_len / hop;
@@ -428,6 +466,19 @@ static FrameArgs frame_args(const paa_proj* h, int L, int T) {
     return a;
 }
 
+static bool fused_geometry(const paa_proj* h) { return h->n_fft == 1024 && h->hop == 256 && h->win == 1024; }
+static SpecArgs spec_args(const paa_proj* h, int L, int T, int out_len) {
+    SpecArgs a{};
+    a.tw = h->d_tw; a.win = h->d_win; a.fm = h->d_fm; a.thr = h->d_thr; a.thr_max = h->d_thr_max;
+    a.part = h->d_part + MAX_PART;
+    a.L = L; a.T = T; a.out_len = out_len;
+    a.bin_hz = (float)((double)h->sr / (double)h->n_fft);
+    return a;
+}
+static int spec_op_of(int norm) {
+    return norm == PAA_NORM_MIN_MAX_FREQS ? SOP_MINMAX : norm == PAA_NORM_MAX_PHON ? SOP_PHON : norm == PAA_NORM_FLETCHER_MUNSON ? SOP_FM : SOP_NONE;
+}
+
 template <int OP>
 static paa_status launch_frames(const paa_proj* h, const FrameArgs& a, int rows, hipStream_t st) {
     const size_t lds = 2 * sizeof(float2) * h->n_fft;
@@ -439,6 +490,11 @@ static paa_status launch_frames(const paa_proj* h, const FrameArgs& a, int rows,
 extern "C" paa_status paa_stft(paa_proj* h, const float* d_x, int B, int L, float* d_out, void* stream) {
     if (!h || !d_x || !d_out) PAA_FAIL(PAA_ERR_ARG, "paa_stft: null argument");
     PAA_TRY(check_rows(h, B, L, "paa_stft"));
+    if (fused_geometry(h)) {
+        SpecArgs sa = spec_args(h, L, 1 + L / h->hop, 0);
+        sa.x = d_x; sa.S_out = d_out;
+        return spec_stft(sa, B, (hipStream_t)stream);
+    }
     FrameArgs a = frame_args(h, L, 1 + L / h->hop);
     a.x = d_x; a.S_out = d_out;
     return launch_frames<OP_STFT>(h, a, B, (hipStream_t)stream);
@@ -450,6 +506,11 @@ extern "C" paa_status paa_istft(paa_proj* h, const float* d_S, int B, int T, flo
     if (B < 1 || B > h->max_batch || (size_t)B * T * h->n_fft > h->frames_floats)
         PAA_FAIL(PAA_ERR_SIZE, "paa_istft: B=%d T=%d exceeds the workspace", B, T);
     hipStream_t st = (hipStream_t)stream;
+    if (fused_geometry(h)) {
+        SpecArgs sa = spec_args(h, 0, T, h->hop * (T - 1));
+        sa.S_in = d_S; sa.out = d_out;
+        return spec_istft(sa, B, st);
+    }
     FrameArgs a = frame_args(h, 0, T);
     a.S_in = d_S;
     PAA_TRY(launch_frames<OP_ISTFT>(h, a, B, st));
@@ -460,13 +521,37 @@ extern "C" paa_status paa_istft(paa_proj* h, const float* d_S, int B, int T, flo
     return PAA_OK;
 }
 
+// d_src == nullptr: in place on d_p.  Otherwise out of place: reads d_src, writes d_p (the two must not overlap).
 static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, int rows_p, const float* d_clean, int B, int L,
-                               const float* d_ext, double ext_numel, void* stream) {
+                               const float* d_ext, double ext_numel, void* stream, const float* d_src = nullptr) {
     if (!h || !prm || !d_p) PAA_FAIL(PAA_ERR_ARG, "paa_project: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int nt = prm->norm_type;
     const int64_t n = (int64_t)rows_p * L;
     if (rows_p < 1 || L < 2) PAA_FAIL(PAA_ERR_SIZE, "paa_project: rows_p=%d L=%d", rows_p, L);
+    if (nt < PAA_NORM_L2 || nt > PAA_NORM_MAX_PHON) PAA_FAIL(PAA_ERR_BAD_NORM, "Unknown norm_type: %d", nt);
+    const bool spectral = nt == PAA_NORM_FLETCHER_MUNSON || nt == PAA_NORM_MIN_MAX_FREQS || nt == PAA_NORM_MAX_PHON;
+    if (spectral && fused_geometry(h)) {
+        // one fused launch STFT -> per-bin op -> iSTFT + overlap-add (spec_kernels.hip), then the scale / copy-back launch
+        PAA_TRY(check_rows(h, rows_p, L, "paa_project"));
+        const int T = 1 + L / h->hop;
+        SpecArgs a = spec_args(h, L, T, L);
+        a.min_f = prm->min_freq_attack; a.max_f = prm->max_freq_attack; a.phon_ref = prm->phon_reference_db;
+        a.x = d_src ? d_src : d_p;
+        a.out = d_src ? d_p : h->d_frames;                     // in place: through the workspace (neighbouring workgroups re-read the halo)
+        int npart = 0;
+        PAA_TRY(spec_project(a, spec_op_of(nt), rows_p, &npart, st));
+        const bool fm = nt == PAA_NORM_FLETCHER_MUNSON;
+        if (fm || !d_src) {
+            hipLaunchKernelGGL(k_spec_finish, dim3(std::min(cdiv(n, (int64_t)RED_NT * 4), 1024)), dim3(RED_NT), 0, st,
+                               (const float*)a.out, d_p, n, (const double*)a.part, fm ? npart : 0, prm->fm_epsilon, h->d_scal);
+            PAA_LAUNCH_CHECK();
+        }
+        return PAA_OK;
+    }
+    if (d_src) {          // generic kernels work in place: copy first
+        PAA_HIP(hipMemcpyAsync(d_p, d_src, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+    }
     switch (nt) {
         case PAA_NORM_FLETCHER_MUNSON:
         case PAA_NORM_MIN_MAX_FREQS:
@@ -534,6 +619,61 @@ static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, i
 extern "C" paa_status paa_project(paa_proj* h, const paa_params* prm, float* d_p, int rows_p, const float* d_clean,
                                   int B, int L, void* stream) {
     return project_impl(h, prm, d_p, rows_p, d_clean, B, L, nullptr, 0.0, stream);
+}
+
+extern "C" paa_status paa_project_to(paa_proj* h, const paa_params* prm, const float* d_src, float* d_dst, int rows_p,
+                                     const float* d_clean, int B, int L, void* stream) {
+    if (!d_src || !d_dst) PAA_FAIL(PAA_ERR_ARG, "paa_project_to: null argument");
+    const float* lo = d_src < d_dst ? d_src : d_dst;
+    const float* hi = d_src < d_dst ? d_dst : d_src;
+    if (rows_p > 0 && L > 0 && lo + (int64_t)rows_p * L > hi) PAA_FAIL(PAA_ERR_ARG, "paa_project_to: source and destination overlap");
+    return project_impl(h, prm, d_dst, rows_p, d_clean, B, L, nullptr, 0.0, stream, d_src);
+}
+
+// core/projections.py:68-159 called directly on a spectrum (the reference's project_min_max_freqs / project_fm_norm /
+// project_phon_level take the complex (B, F, T) STFT tensor): d_S_in, d_S_out (B, T, F) complex64 frame-major
+// (in place allowed); prm->norm_type selects the op.  Works for any frame geometry (pure per-bin arithmetic).
+extern "C" paa_status paa_spectrum_project(paa_proj* h, const paa_params* prm, const float* d_S_in, float* d_S_out, int B, int T,
+                                           void* stream) {
+    if (!h || !prm || !d_S_in || !d_S_out) PAA_FAIL(PAA_ERR_ARG, "paa_spectrum_project: null argument");
+    if (B < 1 || T < 1) PAA_FAIL(PAA_ERR_SIZE, "paa_spectrum_project: B=%d T=%d", B, T);
+    if (h->F != 513) PAA_FAIL(PAA_ERR_ARG, "paa_spectrum_project: n_fft=%d (only 1024 is built)", h->n_fft);
+    const int nt = prm->norm_type;
+    const int op = spec_op_of(nt);
+    if (op == SOP_NONE) PAA_FAIL(PAA_ERR_BAD_NORM, "paa_spectrum_project: norm_type %d is not a frequency-domain projection", nt);
+    hipStream_t st = (hipStream_t)stream;
+    SpecArgs a = spec_args(h, 0, T, 0);
+    a.part = h->d_part;
+    a.min_f = prm->min_freq_attack; a.max_f = prm->max_freq_attack; a.phon_ref = prm->phon_reference_db;
+    a.S_in = d_S_in;
+    if (op != SOP_FM) {
+        a.S_out = d_S_out;
+        return spec_apply(a, op, B, nullptr, nullptr, st);
+    }
+    int npart = 0;
+    a.S_out = nullptr;                                       // pass 1: weighted power only
+    PAA_TRY(spec_apply(a, SOP_FM, B, nullptr, &npart, st));
+    hipLaunchKernelGGL(k_fm_finalize, dim3(1), dim3(RED_NT), 0, st, (const double*)a.part, npart, prm->fm_epsilon, h->d_scal);
+    PAA_LAUNCH_CHECK();
+    a.S_out = d_S_out; a.part = nullptr;                     // pass 2: S * predicated scale
+    return spec_apply(a, SOP_NONE, B, h->d_scal, nullptr, st);
+}
+
+// core/projections.py:83-113 compute_fm_weighted_norm_interp: sqrt(sum |S|^2 w(10 log10(|S|^2 + 1e-10), f)) -> d_out[0]
+extern "C" paa_status paa_fm_weighted_norm(paa_proj* h, const float* d_S, int B, int T, float* d_out, void* stream) {
+    if (!h || !d_S || !d_out) PAA_FAIL(PAA_ERR_ARG, "paa_fm_weighted_norm: null argument");
+    if (B < 1 || T < 1) PAA_FAIL(PAA_ERR_SIZE, "paa_fm_weighted_norm: B=%d T=%d", B, T);
+    if (h->F != 513) PAA_FAIL(PAA_ERR_ARG, "paa_fm_weighted_norm: n_fft=%d (only 1024 is built)", h->n_fft);
+    hipStream_t st = (hipStream_t)stream;
+    SpecArgs a = spec_args(h, 0, T, 0);
+    a.part = h->d_part;
+    a.S_in = d_S; a.S_out = nullptr;
+    int npart = 0;
+    PAA_TRY(spec_apply(a, SOP_FM, B, nullptr, &npart, st));
+    hipLaunchKernelGGL(k_fm_finalize, dim3(1), dim3(RED_NT), 0, st, (const double*)a.part, npart, 0.f, h->d_scal);
+    PAA_LAUNCH_CHECK();
+    PAA_HIP(hipMemcpyAsync(d_out, h->d_scal + 1, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return PAA_OK;
 }
 
 extern "C" paa_status paa_project_ext(paa_proj* h, const paa_params* prm, float* d_p, int rows_p, const float* d_clean_stats,

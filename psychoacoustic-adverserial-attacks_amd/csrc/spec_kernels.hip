@@ -1,0 +1,424 @@
+// Fused frequency-domain projection for gfx950, default frame geometry (n_fft = win = 1024, hop = 256).
+//
+// Replaces, in ONE launch, the reference's  compute_stft -> project_{min_max_freqs,fm_norm,phon_level} -> compute_istft ->
+// _align_to  chain (training_utils/train.py:38-66, core/fourier_transforms.py:20-41, core/projections.py:68-159):
+//
+//  * ONE WAVE PER FRAME.  A real 1024-point frame is a 512-point complex FFT of z[m] = x[2m] + i x[2m+1] plus a split
+//    post-pass; 512 = 8 x 8 x 8, so the FFT is three radix-8 passes with 8 complex values per lane in registers, and
+//    the two transposes between passes go through a 5 KB per-wave LDS buffer with conflict-free layouts
+//    (rows of 72 / 10 complex) — no workgroup barrier inside a frame, twiddles and window in registers.
+//  * The per-bin projection runs on the post-pass registers (bin k and its mirror 512 - k live in one lane), feeds the
+//    inverse pre-pass directly, then three inverse radix-8 passes, window, and the windowed frame stays in LDS.
+//  * A workgroup of NW waves handles NW consecutive frames of one row and overlap-adds them in LDS: output hop-block j
+//    is the sum of frames j-3..j, so NW frames give NW - 3 complete blocks (the 3-frame halo is recomputed by the
+//    neighbouring workgroup); envelope division, the FM scale's partial sum, trimming of the reflect padding and the
+//    zero tail of _align_to happen on the way out.  Windowed frames never touch HBM (the round-1 kernels wrote and
+//    re-read 4 x L floats per row): algorithmic traffic is read p + write p.
+//  * FM norm (projections.py:83-133): the same launch leaves sqrt-free partial sums (one double per workgroup, only
+//    frames the workgroup OWNS are counted); the scale is a predicated factor applied by the copy-back / scale kernel.
+#include <algorithm>
+
+#include "spec_kernels.h"
+
+namespace paa {
+
+namespace {
+
+constexpr int XB = 640;                 // complex slots of one wave's exchange buffer (5120 B)
+constexpr int N = 1024, N2 = 512, HOP = 256, F = 513;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// v * (S i): S = -1 forward, +1 inverse
+template <int S>
+__device__ __forceinline__ float2 muli(float2 v) { return S > 0 ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x); }
+
+// 8-point DFT in registers, e^{S 2 pi i nk / 8}
+template <int S>
+__device__ __forceinline__ void dft8(float2 (&x)[8]) {
+    const float r = 0.70710678118654752f;
+    const float2 a0 = cadd(x[0], x[4]), a1 = csub(x[0], x[4]), a2 = cadd(x[2], x[6]), a3 = csub(x[2], x[6]);
+    const float2 a4 = cadd(x[1], x[5]), a5 = csub(x[1], x[5]), a6 = cadd(x[3], x[7]), a7 = csub(x[3], x[7]);
+    const float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, muli<S>(a3)), b3 = csub(a1, muli<S>(a3));
+    const float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, muli<S>(a7)), b7 = csub(a5, muli<S>(a7));
+    x[0] = cadd(b0, b4); x[4] = csub(b0, b4);
+    x[2] = cadd(b2, muli<S>(b6)); x[6] = csub(b2, muli<S>(b6));
+    const float2 t1 = make_float2(r * (b5.x - S * b5.y), r * (b5.y + S * b5.x));      // b5 (1 + S i) / sqrt 2
+    x[1] = cadd(b1, t1); x[5] = csub(b1, t1);
+    const float2 t3 = make_float2(r * (-b7.x - S * b7.y), r * (-b7.y + S * b7.x));    // b7 (-1 + S i) / sqrt 2
+    x[3] = cadd(b3, t3); x[7] = csub(b3, t3);
+}
+
+// per-lane constants of the wave FFT (lane = a = 8 n1 + n0 in the first pass)
+struct LaneTw {
+    float2 a[7];      // W512^(lane k0), k0 = 1..7
+    float2 b[7];      // W64^((lane & 7) k1), k1 = 1..7
+    float2 p[4];      // e^{-2 pi i k / 1024}, k = 1 + lane + 64 j
+    float2 w[8];      // window at samples 2m, 2m + 1, m = lane + 64 n2
+};
+__device__ __forceinline__ void lane_tw(LaneTw& t, const float2* __restrict__ tw, const float* __restrict__ win, int lane) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        t.a[k - 1] = tw[(2 * lane * k) & 1023];
+        t.b[k - 1] = tw[(16 * (lane & 7) * k) & 1023];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.p[j] = tw[1 + lane + 64 * j];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) t.w[n2] = *reinterpret_cast<const float2*>(win + 2 * (lane + 64 * n2));
+}
+
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// 512-point complex FFT of one wave.  In: x[n2] = z[64 n2 + lane].  Out: x[k2] = Z[lane + 64 k2].
+// S = -1: forward; S = +1: unnormalised inverse.  xb: this wave's exchange buffer.
+template <int S>
+__device__ __forceinline__ void wave_fft512(float2 (&x)[8], float2* xb, const LaneTw& t, int lane) {
+    dft8<S>(x);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) x[k] = cmulf(x[k], S < 0 ? t.a[k - 1] : cconj(t.a[k - 1]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xb[k * 72 + lane] = x[k];                          // E1[k0][a], rows of 72
+    wave_fence();
+    const int k0 = lane >> 3, n0 = lane & 7;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) x[n1] = xb[k0 * 72 + 8 * n1 + n0];
+    wave_fence();
+    dft8<S>(x);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) x[k] = cmulf(x[k], S < 0 ? t.b[k - 1] : cconj(t.b[k - 1]));
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) xb[(k0 + 8 * k1) * 10 + n0] = x[k1];             // E2[t = k0 + 8 k1][n0], rows of 10
+    wave_fence();
+    {
+        const float4* r = reinterpret_cast<const float4*>(xb + lane * 10);           // 80-byte rows: conflict-free ds_read_b128
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = r[q];
+            x[2 * q] = make_float2(v.x, v.y);
+            x[2 * q + 1] = make_float2(v.z, v.w);
+        }
+    }
+    wave_fence();
+    dft8<S>(x);
+}
+
+struct BinCtx {
+    const float* fm; const float* thr; float thr_off;      // thr_off = phon_ref - max(thr)
+    float bin_hz, min_f, max_f;
+};
+
+// projections.py:68-159 on one bin.  FM leaves the bin untouched and returns |S|^2 w in `wsum`.
+template <int OP>
+__device__ __forceinline__ float2 bin_op(float2 v, int k, const BinCtx& c, float& wsum) {
+    if (OP == SOP_MINMAX) {                      // projections.py:68-80: keep bins OUTSIDE [min, max]
+        const float f = (float)k * c.bin_hz;
+        const float m = ((f < c.min_f) || (f > c.max_f)) ? 1.f : 0.f;
+        return make_float2(v.x * m, v.y * m);
+    } else if (OP == SOP_PHON) {                 // projections.py:138-159
+        const float mag = sqrtf(v.x * v.x + v.y * v.y);
+        const float mag_db = 20.f * log10f(mag + 1e-8f);
+        const float thr = c.thr[k] + c.thr_off;
+        const float db = (mag_db > thr) ? thr : mag_db;
+        const float mc = exp10f(db * 0.05f);
+        // mc e^{i angle(S)}: S / |S| is that unit phasor; angle(0) = 0
+        if (mag > 0.f) { const float s = mc / mag; return make_float2(v.x * s, v.y * s); }
+        return make_float2(mc, 0.f);
+    } else if (OP == SOP_FM) {                   // projections.py:83-113: bilinear iso-grid weight at (10 log10(|S|^2 + 1e-10), f_bin)
+        const float mag = sqrtf(v.x * v.x + v.y * v.y);
+        const float pw = mag * mag;
+        const float s = 10.f * log10f(pw + 1e-10f);
+        float w = 1.f;
+        const float w0 = c.fm[k];
+        if (w0 >= 0.f && s >= 0.f && s <= 90.f) {
+            int i = (int)floorf(s * 0.1f);
+            i = i > 8 ? 8 : i;
+            if (s <= 10.f * (float)i && i > 0) i -= 1;       // searchsorted(side='left') - 1
+            const float ys = (s - 10.f * (float)i) * 0.1f;
+            w = c.fm[i * F + k] * (1.f - ys) + c.fm[(i + 1) * F + k] * ys;
+        }
+        wsum += pw * w;
+        return v;
+    }
+    return v;
+}
+
+// One frame, start to end, by one wave.
+//   SRC_SPEC: the spectrum comes from S_in (iSTFT) instead of the waveform;  DST_SPEC: stop after the forward transform and
+//   write the spectrum (STFT).  Otherwise the windowed inverse frame is left in xb as 1024 floats.
+// Returns this lane's share of sum |S|^2 w (FM).
+template <int OP, bool SRC_SPEC, bool DST_SPEC>
+__device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, const LaneTw& tw, float2* xb, int row, int t, int lane) {
+    float2 x[8];
+    float2 Xk[4], Xm[4], X0 = make_float2(0.f, 0.f), XN = make_float2(0.f, 0.f);      // bins k = 1 + lane + 64 j, mirrors 512 - k, DC, Nyquist
+    float wsum = 0.f;
+    if (!SRC_SPEC) {
+        const float* xr = a.x + (size_t)row * a.L;
+        const int s0 = t * HOP - N2;                          // first sample of the frame (center=True: reflect pad 512)
+        const bool inside = s0 >= 0 && s0 + N <= a.L && ((a.L & 1) == 0);
+        if (inside) {
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const float2 v = *reinterpret_cast<const float2*>(xr + s0 + 2 * (lane + 64 * n2));
+                x[n2] = make_float2(v.x * tw.w[n2].x, v.y * tw.w[n2].y);
+            }
+        } else {
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                int i0 = s0 + 2 * (lane + 64 * n2), i1 = i0 + 1;
+                if (i0 < 0) i0 = -i0;
+                if (i0 >= a.L) i0 = 2 * (a.L - 1) - i0;
+                if (i1 < 0) i1 = -i1;
+                if (i1 >= a.L) i1 = 2 * (a.L - 1) - i1;
+                x[n2] = make_float2(xr[i0] * tw.w[n2].x, xr[i1] * tw.w[n2].y);
+            }
+        }
+        wave_fft512<-1>(x, xb, tw, lane);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = x[k2];                   // Z in natural order
+        wave_fence();
+        // split post-pass: X[k] = E + T, X[512 - k] = conj(E - T), E = (Z[k] + conj Z[512-k]) / 2, T = w_k (-i/2)(Z[k] - conj Z[512-k])
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 1 + lane + 64 * j;
+            const float2 za = xb[k], zb = cconj(xb[N2 - k]);
+            const float2 E = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y + zb.y));
+            const float2 dz = csub(za, zb);
+            const float2 O = make_float2(0.5f * dz.y, -0.5f * dz.x);
+            const float2 T = cmulf(tw.p[j], O);
+            Xk[j] = cadd(E, T);
+            Xm[j] = cconj(csub(E, T));
+        }
+        {
+            const float2 z0 = xb[0];
+            X0 = make_float2(z0.x + z0.y, 0.f);
+            XN = make_float2(z0.x - z0.y, 0.f);
+        }
+        wave_fence();
+    } else {
+        const float2* S = reinterpret_cast<const float2*>(a.S_in) + ((size_t)row * a.T + t) * F;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 1 + lane + 64 * j;
+            Xk[j] = S[k];
+            Xm[j] = S[N2 - k];
+        }
+        X0 = S[0];
+        XN = S[N2];
+    }
+    if (DST_SPEC) {
+        float2* S = reinterpret_cast<float2*>(a.S_out) + ((size_t)row * a.T + t) * F;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 1 + lane + 64 * j;
+            S[k] = Xk[j];
+            if (k != N2 - k) S[N2 - k] = Xm[j];
+        }
+        if (lane == 0) { S[0] = X0; S[N2] = XN; }
+        return 0.f;
+    }
+    // ---- per-bin projection (bin 256 is its own mirror: projected once, counted once) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = 1 + lane + 64 * j;
+        Xk[j] = bin_op<OP>(Xk[j], k, c, wsum);
+        if (k != N2 - k) Xm[j] = bin_op<OP>(Xm[j], N2 - k, c, wsum); else Xm[j] = Xk[j];
+    }
+    {
+        float w0 = 0.f;
+        X0 = bin_op<OP>(X0, 0, c, w0);
+        XN = bin_op<OP>(XN, N2, c, w0);
+        if (lane == 0) wsum += w0;
+        X0.y = 0.f; XN.y = 0.f;                               // irfft ignores Im(DC), Im(Nyquist)
+    }
+    // ---- inverse pre-pass: Z'[k] = Ee + i Oo, Z'[512 - k] = conj(Ee - i Oo), Ee = X[k] + conj X[512-k], Oo = (X[k] - conj X[512-k]) conj(w_k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = 1 + lane + 64 * j;
+        const float2 xa = Xk[j], xm = cconj(Xm[j]);
+        const float2 Ee = cadd(xa, xm);
+        const float2 Oo = cmulf(csub(xa, xm), cconj(tw.p[j]));
+        const float2 iO = make_float2(-Oo.y, Oo.x);
+        xb[k] = cadd(Ee, iO);
+        xb[N2 - k] = cconj(csub(Ee, iO));                      // k = 256: both stores carry the same value
+    }
+    if (lane == 0) xb[0] = make_float2(X0.x + XN.x, X0.x - XN.x);
+    wave_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) x[n2] = xb[lane + 64 * n2];
+    wave_fence();
+    wave_fft512<+1>(x, xb, tw, lane);
+    // x[k2] = 1024 z[lane + 64 k2]: samples 2m, 2m + 1 of the frame; window again (istft), keep in LDS
+    const float inv = 1.f / (float)N;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(x[k2].x * inv * tw.w[k2].x, x[k2].y * inv * tw.w[k2].y);
+    return wsum;
+}
+
+// NW frames of one row per workgroup -> NW - 3 output hop-blocks.  grid: (groups, rows).
+template <int OP, bool SRC_SPEC, int NW>
+__global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 xbuf[];                   // [NW][XB]
+    constexpr int NOUT = NW - 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x, row = blockIdx.y;
+    const int c0 = 2 + g * NOUT;                              // first output hop-block (padded-signal block index)
+    const int t = c0 - 3 + wave;                              // this wave's frame
+    float2* xb = xbuf + wave * XB;
+    BinCtx c;
+    c.fm = a.fm; c.thr = a.thr; c.thr_off = a.phon_ref - (OP == SOP_PHON ? a.thr_max[0] : 0.f);
+    c.bin_hz = a.bin_hz; c.min_f = a.min_f; c.max_f = a.max_f;
+    float wsum = 0.f;
+    if (t >= 0 && t < a.T) {
+        LaneTw tw;
+        lane_tw(tw, a.tw, a.win, lane);
+        wsum = wave_frame<OP, SRC_SPEC, false>(a, c, tw, xb, row, t, lane);
+        if (!(wave >= 3 || g == 0)) wsum = 0.f;               // halo frames belong to the previous workgroup's sum
+    } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(0.f, 0.f);
+    }
+    double dsum = 0.0;
+    if (OP == SOP_FM) dsum = wave_sum((double)wsum);
+    __syncthreads();                                          // every frame of the workgroup is in LDS
+    if (OP == SOP_FM) {
+        double* red = reinterpret_cast<double*>(xbuf + NW * XB);
+        if (lane == 0) red[wave] = dsum;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int w = 0; w < NW; ++w) s += red[w];
+            a.part[(size_t)row * gridDim.x + g] = s;
+        }
+    }
+    // overlap-add: block j = c0 + jj <- frames j-3..j = waves jj..jj+3 at offsets 768, 512, 256, 0 (+ r)
+    const float* fb = reinterpret_cast<const float*>(xbuf);
+    const int valid_len = HOP * (a.T - 1);
+    float* outr = a.out + (size_t)row * a.out_len;
+    for (int i = tid; i < NOUT * HOP; i += NW * 64) {
+        const int jj = i >> 8, r = i & 255;
+        const int j = c0 + jj;
+        const int m = HOP * (j - 2) + r;                      // output sample (reflect padding trimmed)
+        if (m >= valid_len) continue;
+        float sum = 0.f, env = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tq = j - 3 + q;
+            if (tq >= 0 && tq < a.T) {
+                const int n = HOP * (3 - q) + r;
+                sum += fb[(jj + q) * (2 * XB) + n];
+                const float w = a.win[n];
+                env += w * w;
+            }
+        }
+        outr[m] = sum / env;
+    }
+    // _align_to (train.py:27-35): samples past the iSTFT length are zero; the last workgroup of the row writes them
+    if (g == (int)gridDim.x - 1)
+        for (int m = valid_len + tid; m < a.out_len; m += NW * 64) outr[m] = 0.f;
+}
+
+// STFT only: one wave per frame, 4 frames per workgroup.  grid: (ceil(T / 4), rows)
+__global__ __launch_bounds__(256) void k_spec_stft(SpecArgs a) {
+    __shared__ __attribute__((aligned(16))) float2 xbuf[4 * XB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x * 4 + wave, row = blockIdx.y;
+    if (t >= a.T) return;
+    LaneTw tw;
+    lane_tw(tw, a.tw, a.win, lane);
+    BinCtx c{};
+    wave_frame<SOP_NONE, false, true>(a, c, tw, xbuf + wave * XB, row, t, lane);
+}
+
+// per-bin op on a spectrum in memory (frame-major (rows, T, F) complex64), optional uniform scale
+template <int OP>
+__global__ __launch_bounds__(256) void k_spec_apply(SpecArgs a, int64_t n, const float* __restrict__ scale) {
+    __shared__ double red[4];
+    BinCtx c;
+    c.fm = a.fm; c.thr = a.thr; c.thr_off = a.phon_ref - (OP == SOP_PHON ? a.thr_max[0] : 0.f);
+    c.bin_hz = a.bin_hz; c.min_f = a.min_f; c.max_f = a.max_f;
+    const float2* S = reinterpret_cast<const float2*>(a.S_in);
+    float2* O = reinterpret_cast<float2*>(a.S_out);
+    const float sc = scale ? scale[0] : 1.f;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % F);
+        float w = 0.f;
+        float2 v = bin_op<OP>(S[i], k, c, w);
+        acc += (double)w;
+        if (O) O[i] = make_float2(v.x * sc, v.y * sc);
+    }
+    if (OP == SOP_FM && a.part) {
+        acc = block_sum<double, 256>(acc, red);
+        if (threadIdx.x == 0) a.part[blockIdx.x] = acc;
+    }
+}
+
+template <int OP, bool SRC_SPEC>
+paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
+    // small batches: many small workgroups (latency); large batches: 16 frames per workgroup (13 / 16 of the FFTs are useful)
+    const int nblk = a.T - 1;                                 // output hop-blocks per row
+    if (rows * cdiv(nblk, 13) >= 256) {
+        constexpr int NW = 16;
+        const size_t lds = sizeof(float2) * NW * XB + 256;
+        static bool attr = false;
+        if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spec_fused<OP, SRC_SPEC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL((k_spec_fused<OP, SRC_SPEC, NW>), dim3(cdiv(nblk, NW - 3), rows), dim3(NW * 64), lds, st, a);
+    } else {
+        constexpr int NW = 8;
+        const size_t lds = sizeof(float2) * NW * XB + 256;
+        hipLaunchKernelGGL((k_spec_fused<OP, SRC_SPEC, NW>), dim3(cdiv(nblk, NW - 3), rows), dim3(NW * 64), lds, st, a);
+    }
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+}  // namespace
+
+int spec_groups(int T, int rows) {
+    const int nblk = T - 1;
+    return rows * cdiv(nblk, 13) >= 256 ? cdiv(nblk, 13) : cdiv(nblk, 5);
+}
+
+paa_status spec_project(const SpecArgs& a, int op, int rows, int* n_part, hipStream_t st) {
+    if (a.T < 2) PAA_FAIL(PAA_ERR_SIZE, "spec_project: T=%d", a.T);
+    if (n_part) *n_part = rows * spec_groups(a.T, rows);
+    switch (op) {
+        case SOP_MINMAX: return launch_fused<SOP_MINMAX, false>(a, rows, st);
+        case SOP_PHON: return launch_fused<SOP_PHON, false>(a, rows, st);
+        case SOP_FM: return launch_fused<SOP_FM, false>(a, rows, st);
+        default: PAA_FAIL(PAA_ERR_BAD_NORM, "spec_project: op %d", op);
+    }
+}
+
+paa_status spec_stft(const SpecArgs& a, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(k_spec_stft, dim3(cdiv(a.T, 4), rows), dim3(256), 0, st, a);
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+paa_status spec_istft(const SpecArgs& a, int rows, hipStream_t st) {
+    if (a.T < 2) PAA_FAIL(PAA_ERR_SIZE, "spec_istft: T=%d", a.T);
+    return launch_fused<SOP_NONE, true>(a, rows, st);
+}
+
+paa_status spec_apply(const SpecArgs& a, int op, int rows, const float* scale, int* n_part, hipStream_t st) {
+    const int64_t n = (int64_t)rows * a.T * F;
+    const int grid = (int)std::min<int64_t>(cdiv(n, 256 * 4), 1024);
+    if (n_part) *n_part = grid;
+    switch (op) {
+        case SOP_NONE: hipLaunchKernelGGL(k_spec_apply<SOP_NONE>, dim3(grid), dim3(256), 0, st, a, n, scale); break;
+        case SOP_MINMAX: hipLaunchKernelGGL(k_spec_apply<SOP_MINMAX>, dim3(grid), dim3(256), 0, st, a, n, scale); break;
+        case SOP_PHON: hipLaunchKernelGGL(k_spec_apply<SOP_PHON>, dim3(grid), dim3(256), 0, st, a, n, scale); break;
+        case SOP_FM: hipLaunchKernelGGL(k_spec_apply<SOP_FM>, dim3(grid), dim3(256), 0, st, a, n, scale); break;
+        default: PAA_FAIL(PAA_ERR_BAD_NORM, "spec_apply: op %d", op);
+    }
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
+}  // namespace paa

@@ -135,6 +135,33 @@ def create_logger(args, logs_root=None):
     return logger, max(chkpt_epoch, 0)
 
 
+def plan_dataset(lengths, seed: int, relative_audio_length: float, target_size: int = 30_000, n_splits: int = 4):
+    """The selection the reference's ``create_data_loaders`` makes (build.py:104-208), as index arithmetic on the clip
+    lengths alone: ``random.seed(seed)``; the clips of the ``n_splits`` dataset splits are concatenated split by split
+    (clip i of the input belongs to split ``i % n_splits`` — the order a caller interleaving LibriSpeech's four splits
+    produces) and shuffled; the first ``target_size`` are kept; ``min_len`` / ``audio_length`` are the 10 % and
+    ``relative_audio_length`` quantiles (torch.quantile, float32, linear interpolation, truncated to int) of the FIRST
+    300 of them; clips outside [min_len, audio_length] are DROPPED (build.py:189 — not cropped); a second shuffle of the
+    survivors' positions gives the 80 / 10 / 10 split.  Returns dict(audio_length, min_len, train, eval, test) with
+    clip indices into ``lengths``; train order is immaterial (the reference's train loader reshuffles every epoch)."""
+    import random
+    rnd = random.Random()
+    rnd.seed(seed)
+    order = [i for k in range(n_splits) for i in range(k, len(lengths), n_splits)]
+    rnd.shuffle(order)
+    order = order[:target_size]
+    head = torch.tensor([float(lengths[i]) for i in order[:min(300, len(order))]], dtype=torch.float32)
+    min_len = int(head.quantile(0.10).item())
+    audio_length = int(head.quantile(float(relative_audio_length)).item())
+    kept = [i for i in order if min_len <= lengths[i] <= audio_length][:target_size]
+    idx = list(range(len(kept)))
+    rnd.shuffle(idx)
+    n_tr, n_ev = int(0.8 * len(idx)), int(0.1 * len(idx))
+    pick = lambda sel: [kept[j] for j in sel]
+    return dict(audio_length=audio_length, min_len=min_len, train=pick(idx[:n_tr]), eval=pick(idx[n_tr:n_tr + n_ev]),
+                test=pick(idx[n_tr + n_ev:]))
+
+
 def percentile_length(lengths, q: float) -> int:
     """build.py:41-61: the clip length every utterance is cropped / right-zero-padded to (q-quantile of the lengths)."""
     return int(np.quantile(np.asarray(lengths, dtype=np.int64), q))
@@ -192,9 +219,16 @@ def create_data_loaders(args):
     bs = int(args.batch_size)
     data_dir = getattr(args, "data_dir", None)
     if data_dir:
+        # the reference's selection: length filter on the quantiles of the first 300 shuffled clips, seeded shuffles,
+        # 80 / 10 / 10 split (build.py:183-208) — plan_dataset; collate = crop / right-zero-pad (build.py:41-61)
         waves, texts = load_local_dataset(data_dir, int(args.sr))
-        length = percentile_length([len(w) for w in waves], float(args.relative_audio_length))
-        x = collate_fixed(waves, length)
+        plan = plan_dataset([len(w) for w in waves], int(args.seed), float(args.relative_audio_length), n_splits=1)
+        length = plan["audio_length"]
+        if getattr(args, "small_data", False):
+            keep = max(3 * bs, len(plan["train"]) // 100)
+            plan = {k: (v[:keep] if isinstance(v, list) else v) for k, v in plan.items()}
+        mk = lambda ids: _batches(collate_fixed([waves[i] for i in ids], length), [texts[i] for i in ids], bs) if ids else []
+        return mk(plan["train"]), mk(plan["eval"]), mk(plan["test"]), length
     else:
         length = int(round(float(getattr(args, "audio_seconds", 10.0)) * int(args.sr)))
         n = bs * int(getattr(args, "steps_per_epoch", 4)) * 10 // 8 + 2 * bs

@@ -41,7 +41,8 @@ def perturbation_constraint(p: torch.Tensor, clean_audio, args, interp, spl_thre
             raise ValueError("SNR projection requires clean_audio ro compare to")           # train.py:91
         if n == "tv" and clean_audio is None:
             raise ValueError("TV projection can benefit from clean_audio for bounds")       # train.py:95
-    q = runtime.as_f32_cuda(p.detach(), "p").clone()
+    src = runtime.as_f32_cuda(p.detach(), "p")
+    q = torch.empty_like(src)
     rows, L = (q.shape[0], q.shape[1]) if q.dim() == 2 else (1, q.shape[0])
     clean = None if clean_audio is None else runtime.as_f32_cuda(clean_audio, "clean_audio")
     if clean is not None and clean.shape[-1] != L:
@@ -49,13 +50,18 @@ def perturbation_constraint(p: torch.Tensor, clean_audio, args, interp, spl_thre
     pr = runtime.get_proj(args, q.device, rows, L, interp)
     out_len = L
     with torch.cuda.device(q.device):
-        for n in norms:
+        for i, n in enumerate(norms):
             a = type("A", (), dict(vars(args)))()
             a.norm_type = n
             if n == "max_phon":
                 pr.set_spl_thresh(spl_thresh)
-            _lib.check(_lib.lib().paa_project(pr.h, runtime.params_of(a), _lib.ptr(q), rows, _lib.ptr(clean),
-                                              0 if clean is None else clean.shape[0], L, _lib.stream_ptr()))
+            nb = 0 if clean is None else clean.shape[0]
+            if i == 0:       # the reference's functions return a new tensor: out of place from p (one fused launch for the FFT norms)
+                _lib.check(_lib.lib().paa_project_to(pr.h, runtime.params_of(a), _lib.ptr(src), _lib.ptr(q), rows, _lib.ptr(clean),
+                                                     nb, L, _lib.stream_ptr()))
+            else:
+                _lib.check(_lib.lib().paa_project(pr.h, runtime.params_of(a), _lib.ptr(q), rows, _lib.ptr(clean), nb, L,
+                                                  _lib.stream_ptr()))
             if n in FREQ_NORMS and clean is None:
                 out_len = pr.hop * (L // pr.hop)        # iSTFT length hop*(T-1); no _align_to without clean audio
     return q if out_len == L else q[..., :out_len]

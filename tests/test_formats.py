@@ -87,9 +87,16 @@ def test_local_dataset_and_split(tmp_path):
     (tmp_path / "x.trans.txt").write_text("\n".join(lines))
     a = _args(data_dir=str(tmp_path), batch_size=4)
     tr, ev, te, L = build.create_data_loaders(a)
-    assert L == int(np.quantile(np.array([3000 + 200 * i for i in range(20)]), 0.8))
-    assert sum(len(t) for _, t in tr) == 16 and sum(len(t) for _, t in ev) == 2 and sum(len(t) for _, t in te) == 2
-    assert tr[0][0].shape == (4, L) and tr[0][1][0] == "HELLO WORLD 0"
+    # the reference DROPS clips outside the [10 %, 80 %] length quantiles (build.py:183-189): 3400..6000 samples survive
+    assert L == int(np.quantile(np.array([3000 + 200 * i for i in range(20)]), 0.8)) == 6040
+    kept = [t for part in (tr, ev, te) for _, texts in part for t in texts]
+    assert sorted(int(t.split()[-1]) for t in kept) == list(range(2, 16))
+    assert sum(len(t) for _, t in tr) == 11 and sum(len(t) for _, t in ev) == 1 and sum(len(t) for _, t in te) == 2
+    assert tr[0][0].shape == (4, L)
+    for x, texts in tr + ev + te:                                     # right zero-pad to L, never cropped here
+        for row, t in zip(x, texts):
+            n = 3000 + 200 * int(t.split()[-1])
+            assert float(row[n:].abs().max()) == 0 and float(row[:n].abs().max()) > 0
     s = _args(batch_size=2, audio_seconds=0.25, steps_per_epoch=3)
     tr, ev, te, L = build.create_data_loaders(s)
     assert L == 4000 and len(tr) >= 3 and len(ev) >= 1 and len(te) >= 1
@@ -101,3 +108,31 @@ def test_scoring_helpers():
     assert scoring_helpers._best_agg([], "targeted") == float("inf")
     with pytest.raises(ValueError):
         scoring_helpers._is_better(1, 2, "sideways")
+
+
+def test_results_json_equals_reference_writer(tmp_path, gold):
+    """tests/golden/results_ref.json was written by the REFERENCE's save.save_json_results (oracle/gen_goldens.py
+    gen_formats); the same call here must give the same file, byte for byte."""
+    save.save_json_results(save_dir=str(tmp_path), norm_type="snr", attack_size="40.0", epoch=3, finished_training=True,
+                           eval_score_clean={"ctc": 1589.123456, "wer": 0.41234567},
+                           eval_score_perturbed={"ctc": 2250.98765, "wer": 0.987654},
+                           train_score={"ctc": 2100.5, "wer": 0.9}, skipped=None,
+                           final_test_clean={"ctc": 1600.0, "wer": 0.4}, final_test_perturbed={"ctc": 2400.0, "wer": 0.9})
+    from conftest import GOLD
+    assert open(tmp_path / "results.json").read() == open(os.path.join(GOLD, "results_ref.json")).read()
+
+
+def test_dataset_plan_equals_reference(gold):
+    """tests/golden/data_plan.json: which clips the reference's create_data_loaders keeps (length filter on the 10 % /
+    relative_audio_length quantiles of the first 300 shuffled clips, build.py:183-189), the clip length, and its
+    80 / 10 / 10 split after the seeded shuffles — produced by running the reference on 400 synthetic clips."""
+    from conftest import GOLD
+    from paa_amd import synth
+    ref = json.load(open(os.path.join(GOLD, "data_plan.json")))
+    u = synth.uniform(synth.key_of("cliplen", 11), ref["n_clips"])
+    lengths = [int(9600 + 40000 * float(v)) for v in u]
+    plan = build.plan_dataset(lengths, ref["seed"], ref["relative_audio_length"])
+    assert plan["audio_length"] == ref["audio_length"] == ref["batch_shape_eval"][1]
+    assert sorted(plan["train"]) == ref["train_ids_sorted"]
+    assert plan["eval"] == ref["eval_ids"] and plan["test"] == ref["test_ids"]
+    assert all(plan["min_len"] <= lengths[i] <= plan["audio_length"] for k in ("train", "eval", "test") for i in plan[k])

@@ -119,3 +119,66 @@ def test_compose_clamp_clamp_box_and_argmax():
     lg[0, 5, 7] = lg[0, 5, 9] = 50.0                                      # a tie: the first maximum wins
     ids = loss_helpers.argmax_ids(lg)
     assert ids.dtype == torch.int16 and torch.equal(ids.long(), torch.argmax(lg, dim=-1)) and int(ids[0, 5]) == 7
+
+
+def test_spectrum_level_functions_vs_reference_goldens(gold):
+    """core/projections.py:68-159 on a complex (B, F, T) tensor, with the reference's argument order
+    (tests/golden/spectrum.npz holds what the reference returns for the same calls)."""
+    g = gold("spectrum.npz")
+    from paa_amd.core import iso
+    interp = iso.build_weight_interpolator()
+    for L, amp in ((4096, 0.3), (5000, 1e-2)):
+        args = _args("fletcher_munson", ["--fm_epsilon", "0.05"])
+        spl = build.init_phon_threshold_tensor(args)
+        p = torch.from_numpy(np.concatenate([synth.perturbation(L) * np.float32(amp), synth.clean_audio(1, L) * np.float32(4.0)], 0)).cuda()
+        S = fourier_transforms.compute_stft(p, args)
+        tag = f"L{L}|a{amp:g}"
+
+        def cmp(got, key, tol=TOL):
+            ref = g[key]
+            assert tuple(got.shape) == tuple(ref.shape[:-1])
+            e = float(np.abs(torch.view_as_real(got.contiguous()).cpu().numpy() - ref).max() / np.abs(ref).max())
+            print(f"{key}: {e:.2e}")
+            assert e <= tol, (key, e)
+        cmp(projections.project_min_max_freqs(args, S, 120.0, 20000.0), f"minmax|{tag}")
+        cmp(projections.project_min_max_freqs(args, S, 500.0, 3000.0), f"minmax_500_3000|{tag}")
+        n = float(projections.compute_fm_weighted_norm_interp(S, interp, args))
+        assert n == pytest.approx(float(g[f"fm_norm|{tag}"][0]), rel=2e-5)
+        cmp(projections.project_fm_norm(S, args, interp), f"fm|{tag}")
+        big = _args("fletcher_munson", ["--fm_epsilon", "1e9"])
+        cmp(projections.project_fm_norm(S, big, interp), f"fm_inactive|{tag}")
+        cmp(projections.project_phon_level(S, args, spl), f"phon|{tag}")
+        # spectrum-level op between the library's own STFT and iSTFT == the fused dispatcher path
+        a2 = _args("max_phon", [])
+        y = fourier_transforms.compute_istft(projections.project_phon_level(S, a2, spl), a2)
+        q = train.perturbation_constraint(p, None, a2, None, spl)
+        assert tuple(y.shape) == tuple(q.shape) and float((y - q).abs().max()) <= 2e-6 * float(q.abs().max())
+
+
+def test_out_of_place_equals_in_place_and_batched_rows():
+    """paa_project_to (one fused launch) against paa_project (workspace + copy-back) on the same input, (1, L) and a
+    (32, L) batch of rows — bit for bit — and the fused kernel's two workgroup shapes (8 / 16 frames) against each other."""
+    from paa_amd import _lib, runtime
+    lib = _lib.lib()
+    L = 160000
+    for norm, extra in (("min_max_freqs", []), ("max_phon", []), ("fletcher_munson", ["--fm_epsilon", "0.5"])):
+        args = _args(norm, extra)
+        spl = build.init_phon_threshold_tensor(args)
+        x = torch.from_numpy(synth.clean_audio(32, L)).cuda() * 0.3
+        pr = runtime.get_proj(args, x.device, 32, L)
+        pr.set_spl_thresh(spl)
+        prm = runtime.params_of(args)
+        for rows in (1, 32):
+            src = x[:rows].contiguous()
+            a = src.clone()
+            _lib.check(lib.paa_project(pr.h, prm, _lib.ptr(a), rows, None, 0, L, _lib.stream_ptr()))
+            b = torch.empty_like(src)
+            _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(src), _lib.ptr(b), rows, None, 0, L, _lib.stream_ptr()))
+            assert torch.equal(a, b), (norm, rows)
+        if norm != "fletcher_munson":          # row 0 of the batch (16-frame workgroups) == the single row (8-frame workgroups)
+            one = torch.empty(1, L, device="cuda"); many = torch.empty(32, L, device="cuda")
+            _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(x[:1].contiguous()), _lib.ptr(one), 1, None, 0, L, _lib.stream_ptr()))
+            _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(x), _lib.ptr(many), 32, None, 0, L, _lib.stream_ptr()))
+            assert torch.equal(one[0], many[0]), norm
+        with pytest.raises(Exception):
+            _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(x), _lib.ptr(x), 32, None, 0, L, _lib.stream_ptr()))

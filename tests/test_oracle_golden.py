@@ -115,3 +115,55 @@ def test_pgd_step(gold, case):
     ok = ~flips.reshape(pn.shape) if flips.shape != pn.shape else ~flips
     assert np.abs(pn - pref)[ok].max() <= 1e-5 * max(np.abs(pref).max(), 1e-30) + 1e-9
     assert opgd.compute_wer(r["logits"], texts) == pytest.approx(float(g["avg_wer"][0]), abs=1e-12)
+
+
+def test_spectrum_level_functions(gold):
+    """core/projections.py:68-159 called on a complex (B, F, T) tensor: oracle vs tests/golden/spectrum.npz (reference)."""
+    g = gold("spectrum.npz")
+    for L, amp in ((4096, 0.3), (5000, 1e-2)):
+        args = cli_to_args("fletcher_munson", ["--fm_epsilon", "0.05"])
+        p = torch.from_numpy(np.concatenate([synth.perturbation(L) * np.float32(amp), synth.clean_audio(1, L) * np.float32(4.0)], 0))
+        S = OP.compute_stft(p, args)
+        tag = f"L{L}|a{amp:g}"
+        cmp = lambda got, key, tol: np.testing.assert_allclose(torch.view_as_real(got.contiguous()).numpy(), g[key], rtol=0,
+                                                               atol=tol * np.abs(g[key]).max())
+        cmp(OP.project_min_max_freqs(args, S), f"minmax|{tag}", 1e-6)
+        a2 = cli_to_args("min_max_freqs", ["--min_freq_attack", "500", "--max_freq_attack", "3000"])
+        cmp(OP.project_min_max_freqs(a2, S), f"minmax_500_3000|{tag}", 1e-6)
+        assert float(OP.fm_weighted_norm(S, args)) == pytest.approx(float(g[f"fm_norm|{tag}"][0]), rel=2e-6)
+        cmp(OP.project_fm_norm(S, args), f"fm|{tag}", 1e-5)
+        cmp(OP.project_fm_norm(S, cli_to_args("fletcher_munson", ["--fm_epsilon", "1e9"])), f"fm_inactive|{tag}", 1e-6)
+        cmp(OP.project_phon_level(S, args, OP.spl_thresh_tensor(args)), f"phon|{tag}", 2e-6)
+
+
+TRAJ_TEXTS = ["ab cd", "hello", "a b c", "xyz w", "the fox", "lazy dog"]
+
+
+@pytest.mark.parametrize("opt", ["pgd", "adam"])
+def test_train_epoch_trajectory(gold, opt):
+    """Two epochs of the reference's train_epoch over three batches (tests/golden/traj_*.npz): the PGD branch and the
+    Adam + StepLR branch (train.py:165-175, build.py:352-359; the scheduler is stepped once per epoch)."""
+    g = gold(f"traj_{opt}.npz")
+    a = A.tiny("group", False)
+    L, B, NB = 8000, 2, 3
+    sd = OW.to_torch(A.rule_weights(a))
+    loader = [(torch.from_numpy(synth.clean_audio(B, L, first_clip=i * B)), TRAJ_TEXTS[i * B:(i + 1) * B]) for i in range(NB)]
+    args = cli_to_args("snr", ["--snr_db", "40"])
+    args.optimizer_type, args.lr = opt, (1e-4 if opt == "pgd" else 2e-4)
+    p = torch.from_numpy(synth.perturbation(L) * np.float32(1e-2))
+    optimizer = scheduler = None
+    if opt == "adam":
+        p = torch.nn.Parameter(p.clone())
+        optimizer = torch.optim.Adam([p], lr=args.lr)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=1, gamma=0.5)
+    for ep in range(2):
+        p, ctc, wer = opgd.train_epoch(sd, a, args, loader, p, optimizer)
+        if scheduler is not None:
+            scheduler.step()
+        ref = g[f"p_epoch{ep}"]
+        got = p.detach().numpy()
+        assert ctc == pytest.approx(float(g[f"ctc_epoch{ep}"][0]), rel=5e-5)
+        assert wer == pytest.approx(float(g[f"wer_epoch{ep}"][0]), abs=1e-9)
+        diff = np.abs(got - ref) / np.abs(ref).max()
+        # PGD: only samples whose gradient sign is numerically undecided in some step may differ (by multiples of 2 lr)
+        assert (diff > 1e-5).mean() < (5e-3 if opt == "pgd" else 1e-3), (ep, diff.max())
