@@ -133,7 +133,13 @@ def pos_conv_weight(sd: dict) -> np.ndarray:
     pc = "wav2vec2.encoder.pos_conv_embed.conv"
     if f"{pc}.weight" in sd:
         return np.asarray(sd[f"{pc}.weight"], dtype=np.float32)
-    g = np.asarray(sd[f"{pc}.parametrizations.weight.original0"], dtype=np.float64)
-    v = np.asarray(sd[f"{pc}.parametrizations.weight.original1"], dtype=np.float64)
+    # torch >= 2.1 parametrization keys, or the legacy weight_g / weight_v pair of the published 960h checkpoint files
+    kg = f"{pc}.parametrizations.weight.original0" if f"{pc}.parametrizations.weight.original0" in sd else f"{pc}.weight_g"
+    kv = f"{pc}.parametrizations.weight.original1" if f"{pc}.parametrizations.weight.original1" in sd else f"{pc}.weight_v"
+    if kg not in sd or kv not in sd:
+        raise KeyError(f"positional conv weight: none of '{pc}.weight', '...parametrizations.weight.original0/1', "
+                       f"'{pc}.weight_g/weight_v' found in the state dict")
+    g = np.asarray(sd[kg], dtype=np.float64)
+    v = np.asarray(sd[kv], dtype=np.float64)
     nrm = np.sqrt((v * v).sum(axis=(0, 1), keepdims=True))
     return (g * v / nrm).astype(np.float32)

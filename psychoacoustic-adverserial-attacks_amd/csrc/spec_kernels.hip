@@ -16,6 +16,8 @@
 //    re-read 4 x L floats per row): algorithmic traffic is read p + write p.
 //  * FM norm (projections.py:83-133): the same launch leaves sqrt-free partial sums (one double per workgroup, only
 //    frames the workgroup OWNS are counted); the scale is a predicated factor applied by the copy-back / scale kernel.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "spec_kernels.h"
@@ -358,11 +360,19 @@ __global__ __launch_bounds__(256) void k_spec_apply(SpecArgs a, int64_t n, const
     }
 }
 
+// 16-frame workgroups (13 / 16 of the FFTs useful, one workgroup per CU) or 8-frame ones (5 / 8 useful, two per CU)
+static bool spec_wide(int T, int rows) {
+    static const int force = [] { const char* e = getenv("PAA_SPEC_NW"); return e ? atoi(e) : 0; }();
+    if (force == 8) return false;
+    if (force == 16) return true;
+    return rows * cdiv(T - 1, 13) >= 256;
+}
+
 template <int OP, bool SRC_SPEC>
 paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
     // small batches: many small workgroups (latency); large batches: 16 frames per workgroup (13 / 16 of the FFTs are useful)
     const int nblk = a.T - 1;                                 // output hop-blocks per row
-    if (rows * cdiv(nblk, 13) >= 256) {
+    if (spec_wide(a.T, rows)) {
         constexpr int NW = 16;
         const size_t lds = sizeof(float2) * NW * XB + 256;
         static bool attr = false;
@@ -381,7 +391,7 @@ paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
 
 int spec_groups(int T, int rows) {
     const int nblk = T - 1;
-    return rows * cdiv(nblk, 13) >= 256 ? cdiv(nblk, 13) : cdiv(nblk, 5);
+    return spec_wide(T, rows) ? cdiv(nblk, 13) : cdiv(nblk, 5);
 }
 
 paa_status spec_project(const SpecArgs& a, int op, int rows, int* n_part, hipStream_t st) {

@@ -63,16 +63,24 @@ class Proj:
 
 
 def get_proj(args, device, rows: int, length: int, interp=None) -> Proj:
+    """One projection context per (device, frame geometry, weight table).  A custom ``iso.WeightTable`` gets a context of
+    its own (its identity is part of the key: it is never silently replaced by the default table); a context that has
+    to grow for a larger batch / length keeps its table and its max_phon contour."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("paa_amd runs on the GPU only (device %r); there is no CPU fallback" % (device,))
+    table = interp if isinstance(interp, iso.WeightTable) else None
     key = (device.index if device.index is not None else torch.cuda.current_device(),
-           int(args.n_fft), int(args.hop_length), int(args.win_length), int(args.sr))
+           int(args.n_fft), int(args.hop_length), int(args.win_length), int(args.sr), id(table) if table is not None else None)
     pr = _PROJ.get(key)
     if pr is None or pr.max_batch < rows or pr.max_len < length:
         mb = max(rows, pr.max_batch if pr else 1)
         ml = max(length, pr.max_len if pr else 1)
-        pr = Proj(device, key[1], key[2], key[3], key[4], mb, ml, interp)
+        new = Proj(device, key[1], key[2], key[3], key[4], mb, ml, table)
+        new._table = table                      # keeps the table alive: its id is in the key
+        if pr is not None and getattr(pr, "_thr_ref", None) is not None:
+            new.set_spl_thresh(pr._thr_ref)
+        pr = new
         _PROJ[key] = pr
     return pr
 

@@ -91,3 +91,21 @@ def test_padded_layout_base():
     assert P == [32000, 16000, 8000, 4000, 2000, 1000, 500]
     T, P = padded_rows(A.BASE, 480000)
     assert T[-1] == 1499 and all(p >= t for p, t in zip(P, T))
+
+
+def test_pos_conv_weight_key_aliases():
+    """The weight-norm fold accepts the folded weight, the torch >= 2.1 parametrization keys and the legacy
+    weight_g / weight_v pair (raw 960h checkpoint files) — same result."""
+    a = A.tiny()
+    sd = A.rule_weights(a)
+    pc = "wav2vec2.encoder.pos_conv_embed.conv"
+    w = A.pos_conv_weight(sd)
+    legacy = {k: v for k, v in sd.items() if "parametrizations" not in k}
+    legacy[f"{pc}.weight_g"] = sd[f"{pc}.parametrizations.weight.original0"]
+    legacy[f"{pc}.weight_v"] = sd[f"{pc}.parametrizations.weight.original1"]
+    np.testing.assert_array_equal(A.pos_conv_weight(legacy), w)
+    folded = {f"{pc}.weight": w}
+    np.testing.assert_array_equal(A.pos_conv_weight(folded), w)
+    import pytest
+    with pytest.raises(KeyError):
+        A.pos_conv_weight({})

@@ -22,7 +22,7 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
+        name = re.sub(r"\([^()]*\)$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).strip()
         tot[name] += float(r["Counter_Value"])
         cnt[name] += 1
     return tot, cnt
