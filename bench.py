@@ -36,7 +36,7 @@ VARIANTS = {v: (f"k_gemm_bf<{'256' if v & 32 else '128'},{'64' if v & 8 else '12
                 f"k_gemm<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'},A{'k' if v & 2 else 'm'},B{'k' if v & 1 else 'n'}>")
             for v in range(64)}
 VARIANTS.update({51: "k_gemm_bf<256,128,bf16>", 55: "k_gemm_bf<256,128,split>", 59: "k_gemm_bf<192,128,bf16>",
-                 40: "k_gemm_win<bf16>", 44: "k_gemm_win<split>", 60: "k_gemm_ring<256,256,bf16>", 61: "k_gemm_ring<256,256,split>"})
+                 40: "k_gemm_win<bf16>", 44: "k_gemm_win<split>", 60: "k_gemm_ring<bf16>", 61: "k_gemm_ring<192,128,split>"})
 DTYPE_NAME = {"fp32": "bf16x3 (split-bf16 hi+lo, three MFMA passes, f32 accumulate: fp32-parity)", "bf16": "bf16"}
 MFMA_PEAK = 2500.0       # dense bf16 TFLOP/s (MI355X_MICROARCH.md); a split-mode product issues three such MFMAs
 
@@ -291,13 +291,13 @@ def main():
         passes = 3 if dtype == "fp32" else 1
         roofline = None
         if prof_on:
-            out = (C.c_double * 192)()
+            out = (C.c_double * 256)()
             _lib.check(lib.paa_prof_read(out))
             lib.paa_prof_enable(0)
-            rows = [(v, out[3 * v], out[3 * v + 1], out[3 * v + 2]) for v in range(64) if out[3 * v] > 0]
+            rows = [(v, out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]) for v in range(64) if out[4 * v] > 0]
             rows.sort(key=lambda r: -r[2])
             if rows:
-                v, n, ms, fl = rows[0]
+                v, n, ms, fl, by = rows[0]
                 achieved = fl / (ms * 1e-3) / 1e12           # ALGORITHMIC flops (2 M N K) per second
                 traffic = None
                 if ar.pmc_json:                              # HBM bytes per launch from separate rocprofv3 --pmc passes of this commit
@@ -311,11 +311,13 @@ def main():
                         traffic = None
                 roofline = {"bound": "mfma", "kernel": VARIANTS[v], "achieved": round(achieved, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
                             "frac": round(achieved / MFMA_PEAK, 4), "traffic": traffic, "launches": int(n),
-                            "avg_launch_us": round(ms * 1e3 / n, 2),
+                            "avg_launch_us": round(ms * 1e3 / n, 2), "algorithmic_bytes_per_launch": int(by / n),
+                            "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1),
                             "mfma_passes_per_product": passes, "mfma_issue_frac": round(passes * achieved / MFMA_PEAK, 4),
                             "sampled_steps": n_prof, "share_of_step": round(ms * 1e-3 / (dt * n_prof / ar.steps), 4),
                             "all_gemm_variants": [{"kernel": VARIANTS[r[0]], "launches": int(r[1]), "ms": round(r[2], 3),
-                                                   "tflops": round(r[3] / (r[2] * 1e-3) / 1e12, 2)} for r in rows]}
+                                                   "tflops": round(r[3] / (r[2] * 1e-3) / 1e12, 2),
+                                                   "algorithmic_MB_per_launch": round(r[4] / r[1] / 1e6, 1)} for r in rows]}
         fl_step = 2.0 * a.fwd_flops_per_clip(L) * B
         res = {"value": round(world * ar.steps / dt, 4), "ms_per_step": round(1e3 * dt / ar.steps, 3), "timed_region_s": round(dt, 3),
                "dtype": DTYPE_NAME[dtype], "model_tflops_achieved_per_gpu": round(fl_step / (dt / ar.steps) / 1e12, 2),

@@ -173,12 +173,13 @@ paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
  * (csrc/gemm_ring.hip).  Results are bit-identical across configurations (same K order); tests assert that. */
 void paa_gemm_config(int ring_mode);
 /* Measurement aid (bench.py roofline leg): HIP-event timing of every GEMM launch on its own stream.
- * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[64][3] =
- * {launches, total ms, total algorithmic FLOP (2*M*N*K*batch)} per kernel variant
+ * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[64][4] =
+ * {launches, total ms, total algorithmic FLOP (2*M*N*K*batch), total algorithmic HBM bytes (every operand and result
+ * byte of the descriptor once)} per kernel variant
  * (tall*32 + bf16_operands*16 + (narrow | 192-row tall tile)*8 + split*4 + a_kcontig*2 + b_kcontig; 40 / 44 = slab kernel
- * of the grouped positional convolution) and resets. */
+ * of the grouped positional convolution; 60 / 61 = LDS-DMA ring kernels, bf16 / split) and resets. */
 paa_status paa_prof_enable(int max_launches);
-paa_status paa_prof_read(double* out192);
+paa_status paa_prof_read(double* out256);
 /* paa_prof_pause(1) stops recording without releasing the events, paa_prof_pause(0) resumes: bench.py creates the
  * events before its timed region and records on the LAST timed step only (the first timing event recorded on a HIP
  * stream switches its queue to profiled dispatch for good, which costs ~4 % on every later launch). */

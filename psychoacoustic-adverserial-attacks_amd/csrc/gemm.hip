@@ -614,7 +614,7 @@ static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
 struct GemmProf {
     bool on = false;
     std::vector<hipEvent_t> ev;
-    std::vector<double> flops;
+    std::vector<double> flops, bytes;
     std::vector<int> variant;
     size_t n = 0, cap = 0;
 };
@@ -691,6 +691,19 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
         g_prof.flops[g_prof.n] = 2.0 * d.M * d.N * (double)d.K * d.batch;
+        {   // algorithmic HBM bytes of this product: every operand / result byte once (overlapping conv rows counted once)
+            const double es = d.operand_bf16 ? 2.0 * (d.precision ? 2 : 1) : 4.0;
+            const double a_el = (d.a_kcontig && d.lda > 0 && d.lda < d.K && !d.a_window && d.a_kseg <= 0) ? ((double)(d.M - 1) * d.lda + d.K) : (double)d.M * d.K;
+            const double mn = (double)d.M * d.N;
+            double by = a_el * es + (double)d.N * d.K * es;
+            if (d.a_window) by = (double)d.a_rows_valid * d.a_kseg * es + (double)d.N * d.K * es;
+            if (d.C) by += mn * 4.0 * (d.accumulate ? 2 : 1);
+            if (d.Cb) by += mn * 2.0 * (d.Cb_lo ? 2 : 1);
+            if (d.C_pre) by += mn * (d.aux_bf16 ? 2.0 : 4.0);
+            if (d.aux) by += mn * (d.aux_bf16 ? 2.0 : 4.0);
+            if (d.residual) by += mn * 4.0;
+            g_prof.bytes[g_prof.n] = by * d.batch;
+        }
         g_prof.variant[g_prof.n] = (tall ? 32 : 0) + (d.operand_bf16 ? 16 : 0) + ((narrow || bm192) ? 8 : 0) + (d.precision ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     }
     // grouped positional convolution (and its dgrad): slab kernel
@@ -757,25 +770,27 @@ extern "C" paa_status paa_prof_enable(int max_launches) {
     g_prof.ev.resize(2 * (size_t)max_launches);
     for (auto& e : g_prof.ev) PAA_HIP(hipEventCreate(&e));
     g_prof.flops.assign(max_launches, 0.0);
+    g_prof.bytes.assign(max_launches, 0.0);
     g_prof.variant.assign(max_launches, 0);
     g_prof.cap = max_launches; g_prof.on = true;
     return PAA_OK;
 }
 
-// out[64][3] = per kernel variant (tall*32 + bf16_operands*16 + (narrow | tall-with-192-rows)*8 + split*4 + a_kcontig*2 + b_kcontig;
-// 40 / 44: the slab kernel of the grouped positional convolution, bf16 / split).
+// out[64][4] = per kernel variant {launches, total ms, total algorithmic FLOP, total algorithmic HBM bytes}
+// (variant = tall*32 + bf16_operands*16 + (narrow | tall-with-192-rows)*8 + split*4 + a_kcontig*2 + b_kcontig; 40 / 44: the slab
+// kernel of the grouped positional convolution, bf16 / split; 60 / 61: the LDS-DMA ring kernels, bf16 / split).
 // Synchronises on the last recorded event.  Resets the counters.
-extern "C" paa_status paa_prof_read(double* out96) {
+extern "C" paa_status paa_prof_read(double* out256) {
     using namespace paa;
-    if (!out96) PAA_FAIL(PAA_ERR_ARG, "paa_prof_read: null");
-    for (int i = 0; i < 192; ++i) out96[i] = 0.0;
+    if (!out256) PAA_FAIL(PAA_ERR_ARG, "paa_prof_read: null");
+    for (int i = 0; i < 256; ++i) out256[i] = 0.0;
     if (g_prof.n == 0) return PAA_OK;
     PAA_HIP(hipEventSynchronize(g_prof.ev[2 * g_prof.n - 1]));
     for (size_t i = 0; i < g_prof.n; ++i) {
         float ms = 0.f;
         PAA_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
         const int v = g_prof.variant[i];
-        out96[3 * v] += 1.0; out96[3 * v + 1] += ms; out96[3 * v + 2] += g_prof.flops[i];
+        out256[4 * v] += 1.0; out256[4 * v + 1] += ms; out256[4 * v + 2] += g_prof.flops[i]; out256[4 * v + 3] += g_prof.bytes[i];
     }
     g_prof.n = 0;
     return PAA_OK;
