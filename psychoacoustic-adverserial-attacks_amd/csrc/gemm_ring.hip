@@ -261,17 +261,18 @@ void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
         case 5: launch_ring<256, 256, 32, 0, 4, 2, 4, true>(g, st); break;      // bf16, 4 stages, certified one ahead
         case 6: launch_ring<256, 128, 32, 1, 3, 4, 2, true>(g, st); break;      // split, 3 stages, certified one ahead
         case 7: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2>(g, st); break;  // split, 192-row tiles, 2 x 40 KB, two workgroups per CU
+        case 8: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2>(g, st); break;  // bf16, 192-row tiles, 2 x 40 KB, two workgroups per CU
         default: break;
     }
 }
 
-int ring_tile_rows(int cfg) { return cfg == 7 ? 192 : 256; }
-int ring_tile_cols(int cfg) { return (cfg == 4 || cfg == 6 || cfg == 7) ? 128 : 256; }
+int ring_tile_rows(int cfg) { return (cfg == 7 || cfg == 8) ? 192 : 256; }
+int ring_tile_cols(int cfg) { return (cfg == 4 || cfg == 6 || cfg == 7 || cfg == 8) ? 128 : 256; }
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
-    if (cfg < 2 || cfg > 7) return false;
+    if (cfg < 2 || cfg > 8) return false;
     const bool split = cfg == 4 || cfg == 6 || cfg == 7;
     if (split != (d.precision != 0)) return false;
-    const int bk = cfg == 2 ? 64 : 32;
+    const int bk = (cfg == 2 || cfg == 8) ? 64 : 32;
     return d.K % bk == 0 && d.K >= 4 * bk;
 }
 
