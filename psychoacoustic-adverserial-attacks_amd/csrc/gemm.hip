@@ -679,6 +679,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             const int64_t r192 = (t192 + 2 * slots - 1) / (2 * slots);             // rounds of 192 x 128 tiles, two per CU
             const double c256 = (double)r256 * 256.0, c192 = (double)r192 * 192.0 * 2.0;
             ring = (c192 < 0.95 * c256 || d.M >= 200000) ? 7 : 0;
+        } else if (bm192 || d.M >= 400000) {
+            ring = 8;             // bf16: wherever 192-row tiles fill the grid better (N = 768 / 2304: +3..10 %) and on the longest conv products (+2..4 %)
         }
         if (ring && !ring_cfg_ok(ring, d)) ring = 0;
         (void)t256;
