@@ -360,39 +360,40 @@ __global__ __launch_bounds__(256) void k_spec_apply(SpecArgs a, int64_t n, const
     }
 }
 
-// 16-frame workgroups (13 / 16 of the FFTs useful, one workgroup per CU) or 8-frame ones (5 / 8 useful, two per CU)
-static bool spec_wide(int T, int rows) {
+// Frames per workgroup: 16 (13 / 16 of the FFTs useful, one workgroup per CU) for batches, 8 (5 / 8 useful, two per CU)
+// otherwise.  4 (one hop-block per workgroup) was measured SLOWER at (1, 160000): 10.2 vs 9.1 us — four times the FFTs for
+// no shorter critical path; it stays reachable through PAA_SPEC_NW for experiments.
+static int spec_nw(int T, int rows) {
     static const int force = [] { const char* e = getenv("PAA_SPEC_NW"); return e ? atoi(e) : 0; }();
-    if (force == 8) return false;
-    if (force == 16) return true;
-    return rows * cdiv(T - 1, 13) >= 256;
+    if (force == 4 || force == 8 || force == 16) return force;
+    return rows * cdiv(T - 1, 13) >= 256 ? 16 : 8;
 }
 
-template <int OP, bool SRC_SPEC>
-paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
-    // small batches: many small workgroups (latency); large batches: 16 frames per workgroup (13 / 16 of the FFTs are useful)
+template <int OP, bool SRC_SPEC, int NW>
+paa_status launch_fused_nw(const SpecArgs& a, int rows, hipStream_t st) {
     const int nblk = a.T - 1;                                 // output hop-blocks per row
-    if (spec_wide(a.T, rows)) {
-        constexpr int NW = 16;
-        const size_t lds = sizeof(float2) * NW * XB + 256;
+    const size_t lds = sizeof(float2) * NW * XB + 256;
+    if (lds > 64 * 1024) {
         static bool attr = false;
         if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spec_fused<OP, SRC_SPEC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-        hipLaunchKernelGGL((k_spec_fused<OP, SRC_SPEC, NW>), dim3(cdiv(nblk, NW - 3), rows), dim3(NW * 64), lds, st, a);
-    } else {
-        constexpr int NW = 8;
-        const size_t lds = sizeof(float2) * NW * XB + 256;
-        hipLaunchKernelGGL((k_spec_fused<OP, SRC_SPEC, NW>), dim3(cdiv(nblk, NW - 3), rows), dim3(NW * 64), lds, st, a);
     }
+    hipLaunchKernelGGL((k_spec_fused<OP, SRC_SPEC, NW>), dim3(cdiv(nblk, NW - 3), rows), dim3(NW * 64), lds, st, a);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
 
+template <int OP, bool SRC_SPEC>
+paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
+    switch (spec_nw(a.T, rows)) {
+        case 16: return launch_fused_nw<OP, SRC_SPEC, 16>(a, rows, st);
+        case 8: return launch_fused_nw<OP, SRC_SPEC, 8>(a, rows, st);
+        default: return launch_fused_nw<OP, SRC_SPEC, 4>(a, rows, st);
+    }
+}
+
 }  // namespace
 
-int spec_groups(int T, int rows) {
-    const int nblk = T - 1;
-    return spec_wide(T, rows) ? cdiv(nblk, 13) : cdiv(nblk, 5);
-}
+int spec_groups(int T, int rows) { return cdiv(T - 1, spec_nw(T, rows) - 3); }
 
 paa_status spec_project(const SpecArgs& a, int op, int rows, int* n_part, hipStream_t st) {
     if (a.T < 2) PAA_FAIL(PAA_ERR_SIZE, "spec_project: T=%d", a.T);
