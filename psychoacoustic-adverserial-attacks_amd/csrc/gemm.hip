@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
             int te = tid;
             asm volatile("" : "+v"(te));
             const int el = te & 63, ew = te >> 6;
-            if constexpr (VEC) epilogue_vec<MI, PREC == 0>(d, acc, cur.m0 + (ew >> 1) * (32 * MI), cur.n0 + (ew & 1) * (BN / 2), cur.z1, cur.z2, el);
+            if constexpr (VEC) epilogue_vec<MI, true>(d, acc, cur.m0 + (ew >> 1) * (32 * MI), cur.n0 + (ew & 1) * (BN / 2), cur.z1, cur.z2, el);
             else epilogue<NJ, MI>(d, acc, cur.m0 + (ew >> 1) * (32 * MI) + 4 * (el >> 5), cur.n0 + (ew & 1) * (BN / 2) + (el & 31), cur.z1, cur.z2);
         }
         if (!more) break;

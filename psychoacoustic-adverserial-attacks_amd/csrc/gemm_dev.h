@@ -124,6 +124,10 @@ __device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, 
     if (o2) { x0 = s; x1 = t; } else { x2 = s; x3 = t; }
 }
 
+// FAST: GELU / GELU' through the branch-free Abramowitz-Stegun erf (|error| <= 1.5e-7 absolute, paa_common.h) instead of
+// libm's erff.  Since round 2 BOTH precision modes take it in the vector epilogue: the split-bf16 products themselves
+// carry ~2^-16 = 1.5e-5 relative error, a hundred times the erf approximation's, and exact erff made the epilogue of the
+// short-K GELU products (FFN up-projection: 96 outputs per lane x ~50 instructions) as long as their MFMA stream.
 // `ex` is the one extra f32 operand stream of the epilogue: aux (GELU_GRAD) or the residual — the host takes the
 // scalar epilogue when a product asks for both.  All per-lane addresses are 32-bit element offsets from uniform bases.
 template <int MI, bool FAST>

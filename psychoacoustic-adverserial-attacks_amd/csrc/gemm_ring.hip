@@ -231,7 +231,7 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
                     }
                 }
         }
-        epilogue_vec<MI, PREC == 0>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
+        epilogue_vec<MI, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
     }
 }
 
