@@ -667,10 +667,10 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     int ring = 0;
     if (tall && g_ring_mode != 1 && d.N >= 128) {
         const int64_t t256 = (int64_t)cdiv(d.M, 256) * cdiv(d.N, 256) * d.batch, t128 = (int64_t)cdiv(d.M, 256) * cdiv(d.N, 128) * d.batch;
-        // Measured on the step's shapes (tools/gemm_ring_bench.py, profiles/r2_gemm_ab.txt): in split mode the 192 x 128
-        // ring kernel at two workgroups per CU wins wherever 256-row tiles leave the persistent grid's last round
-        // part-empty (N = 768: 378 tiles on 256 slots, +15..22 %) and on the long conv products; everywhere else, and in
-        // bf16 mode, the ring kernels only tie the register-staged ones (within 3 %), which stay the default.
+        // Measured on the step's shapes (tools/gemm_ring_bench.py, profiles/r2_gemm_ab.txt): the 192 x 128 ring kernels at
+        // two workgroups per CU win wherever 256-row tiles leave the persistent grid's last round part-empty (N = 768:
+        // 378 tiles on 256 slots, +15..22 % split, +5..10 % bf16; N = 2304: +3..10 %); everywhere else the ring kernels
+        // only tie the register-staged ones (within 3 %), which stay the default.
         if (g_ring_mode >= 2) ring = g_ring_mode;
         else if (d.precision) {
             const int64_t slots = 256;
@@ -678,9 +678,9 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             const int64_t t192 = (int64_t)cdiv(d.M, 192) * cdiv(d.N, 128) * d.batch;
             const int64_t r192 = (t192 + 2 * slots - 1) / (2 * slots);             // rounds of 192 x 128 tiles, two per CU
             const double c256 = (double)r256 * 256.0, c192 = (double)r192 * 192.0 * 2.0;
-            ring = (c192 < 0.95 * c256 || d.M >= 200000) ? 7 : 0;
-        } else if (bm192 || d.M >= 400000) {
-            ring = 8;             // bf16: wherever 192-row tiles fill the grid better (N = 768 / 2304: +3..10 %) and on the longest conv products (+2..4 %)
+            ring = (c192 < 0.95 * c256) ? 7 : 0;      // the long conv products stay on the 256 x 128 kernel (3..8 % faster there since its GELU went branch-free)
+        } else if (bm192) {
+            ring = 8;             // bf16: wherever 192-row tiles fill the grid better (N = 768 / 2304: +3..10 %)
         }
         if (ring && !ring_cfg_ok(ring, d)) ring = 0;
         (void)t256;

@@ -26,7 +26,22 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // be read from LDS under the last MFMAs of the current one and the MFMAs after a barrier start at once instead of
 // waiting out an LDS round trip that all eight lock-stepped waves would sit through together; costs one stage of
 // prefetch distance (NST - 2 stages in flight instead of NST - 1).
-template <int BM, int BN, int BK, int PREC, int NST, int WR, int WC, bool AHEAD, int WPS = 2>
+// MF16 (probe, WRONG RESULTS): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs of the same flops on the same fragments,
+// to time the MFMA shape inside this loop before investing in a 16x16 fragment layout and epilogue.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool MF16>
+__device__ __forceinline__ void mfma_step(const bf16x8& a, const bf16x8& b, f32x16& c) {
+    if constexpr (!MF16) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    } else {
+        f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, hi, 0, 0, 0);
+        c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3]; c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+    }
+}
+
+template <int BM, int BN, int BK, int PREC, int NST, int WR, int WC, bool AHEAD, int WPS = 2, bool MF16 = false>
 __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     constexpr int NW = WR * WC;
     constexpr int NPL = PREC ? 2 : 1;
@@ -209,10 +224,10 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         if (PREC) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                            mfma_step<MF16>(al, bh[j], acc[i][j]);
+                            mfma_step<MF16>(ah, bl[j], acc[i][j]);
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                        mfma_step<MF16>(ah, bh[j], acc[i][j]);
                     }
                     __builtin_amdgcn_s_setprio(0);
                     if (nks < KS) {
@@ -245,12 +260,12 @@ static int ring_resident_blocks(K kernel, int threads) {
     return cus * per;
 }
 
-template <int BM, int BN, int BK, int PREC, int NST, int WR, int WC, bool AHEAD, int WPS = 2>
+template <int BM, int BN, int BK, int PREC, int NST, int WR, int WC, bool AHEAD, int WPS = 2, bool MF16 = false>
 static void launch_ring(const GemmArgs& g, hipStream_t st) {
-    static const int resident = ring_resident_blocks(k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS>, WR * WC * 64);
+    static const int resident = ring_resident_blocks(k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS, MF16>, WR * WC * 64);
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
-    hipLaunchKernelGGL((k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
+    hipLaunchKernelGGL((k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS, MF16>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
 }
 
 void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
@@ -262,17 +277,19 @@ void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
         case 6: launch_ring<256, 128, 32, 1, 3, 4, 2, true>(g, st); break;      // split, 3 stages, certified one ahead
         case 7: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2>(g, st); break;  // split, 192-row tiles, 2 x 40 KB, two workgroups per CU
         case 8: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2>(g, st); break;  // bf16, 192-row tiles, 2 x 40 KB, two workgroups per CU
+        case 9: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2, true>(g, st); break;    // PROBE (wrong results): cfg 7 with 16x16x32 MFMAs
+        case 10: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2, true>(g, st); break;   // PROBE (wrong results): cfg 8 with 16x16x32 MFMAs
         default: break;
     }
 }
 
-int ring_tile_rows(int cfg) { return (cfg == 7 || cfg == 8) ? 192 : 256; }
-int ring_tile_cols(int cfg) { return (cfg == 4 || cfg == 6 || cfg == 7 || cfg == 8) ? 128 : 256; }
+int ring_tile_rows(int cfg) { return (cfg >= 7) ? 192 : 256; }
+int ring_tile_cols(int cfg) { return (cfg == 4 || cfg >= 6) ? 128 : 256; }
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
-    if (cfg < 2 || cfg > 8) return false;
-    const bool split = cfg == 4 || cfg == 6 || cfg == 7;
+    if (cfg < 2 || cfg > 10) return false;
+    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9;
     if (split != (d.precision != 0)) return false;
-    const int bk = (cfg == 2 || cfg == 8) ? 64 : 32;
+    const int bk = (cfg == 2 || cfg == 8 || cfg == 10) ? 64 : 32;
     return d.K % bk == 0 && d.K >= 4 * bk;
 }
 
