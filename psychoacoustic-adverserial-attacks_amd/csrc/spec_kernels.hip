@@ -306,14 +306,22 @@ __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
         const int m = HOP * (j - 2) + r;                      // output sample (reflect padding trimmed)
         if (m >= valid_len) continue;
         float sum = 0.f, env = 0.f;
+        if (j >= 3 && j < a.T) {
+            // interior: all four frames exist and the periodic Hann window's squared overlap-add is exactly 3/2
+            // (sum over the four quarter-period shifts of (1/2 - 1/2 cos)^2: the cos and cos 2x terms cancel)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int tq = j - 3 + q;
-            if (tq >= 0 && tq < a.T) {
-                const int n = HOP * (3 - q) + r;
-                sum += fb[(jj + q) * (2 * XB) + n];
-                const float w = a.win[n];
-                env += w * w;
+            for (int q = 0; q < 4; ++q) sum += fb[(jj + q) * (2 * XB) + HOP * (3 - q) + r];
+            env = 1.5f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tq = j - 3 + q;
+                if (tq >= 0 && tq < a.T) {
+                    const int n = HOP * (3 - q) + r;
+                    sum += fb[(jj + q) * (2 * XB) + n];
+                    const float w = a.win[n];
+                    env += w * w;
+                }
             }
         }
         outr[m] = sum / env;
