@@ -120,18 +120,20 @@ __device__ __forceinline__ float2 bin_op(float2 v, int k, const BinCtx& c, float
         const float m = ((f < c.min_f) || (f > c.max_f)) ? 1.f : 0.f;
         return make_float2(v.x * m, v.y * m);
     } else if (OP == SOP_PHON) {                 // projections.py:138-159
+        // log10 / exp10 through the hardware log2 / exp2 (arguments are normal and far from overflow here): the absolute
+        // error of 20 log10(.) stays at the rounding of its own result (~1e-6 dB), as with libm's log10f
         const float mag = sqrtf(v.x * v.x + v.y * v.y);
-        const float mag_db = 20.f * log10f(mag + 1e-8f);
+        const float mag_db = 6.02059991327962390f * __builtin_amdgcn_logf(mag + 1e-8f);            // 20 log10(2) log2(x)
         const float thr = c.thr[k] + c.thr_off;
         const float db = (mag_db > thr) ? thr : mag_db;
-        const float mc = exp10f(db * 0.05f);
+        const float mc = __builtin_amdgcn_exp2f(db * 0.166096404744368118f);                          // 10^(db / 20)
         // mc e^{i angle(S)}: S / |S| is that unit phasor; angle(0) = 0
         if (mag > 0.f) { const float s = mc / mag; return make_float2(v.x * s, v.y * s); }
         return make_float2(mc, 0.f);
     } else if (OP == SOP_FM) {                   // projections.py:83-113: bilinear iso-grid weight at (10 log10(|S|^2 + 1e-10), f_bin)
         const float mag = sqrtf(v.x * v.x + v.y * v.y);
         const float pw = mag * mag;
-        const float s = 10.f * log10f(pw + 1e-10f);
+        const float s = 3.01029995663981195f * __builtin_amdgcn_logf(pw + 1e-10f);                   // 10 log10(x) via log2
         float w = 1.f;
         const float w0 = c.fm[k];
         if (w0 >= 0.f && s >= 0.f && s <= 90.f) {
@@ -273,6 +275,14 @@ __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
     BinCtx c;
     c.fm = a.fm; c.thr = a.thr; c.thr_off = a.phon_ref - (OP == SOP_PHON ? a.thr_max[0] : 0.f);
     c.bin_hz = a.bin_hz; c.min_f = a.min_f; c.max_f = a.max_f;
+    if (OP == SOP_FM && NW == 16) {
+        // batched shape: the 10 x 513 weight table goes to LDS once per workgroup: the per-bin lookups (row chosen by the bin's own level)
+        // were three dependent global loads per bin on the frame's critical path
+        float* fml = reinterpret_cast<float*>(xbuf + NW * XB) + 64;
+        for (int i = tid; i < 10 * F; i += NW * 64) fml[i] = a.fm[i];
+        c.fm = fml;
+        __syncthreads();
+    }
     float wsum = 0.f;
     if (t >= 0 && t < a.T) {
         LaneTw tw;
@@ -380,7 +390,7 @@ static int spec_nw(int T, int rows) {
 template <int OP, bool SRC_SPEC, int NW>
 paa_status launch_fused_nw(const SpecArgs& a, int rows, hipStream_t st) {
     const int nblk = a.T - 1;                                 // output hop-blocks per row
-    const size_t lds = sizeof(float2) * NW * XB + 256;
+    const size_t lds = sizeof(float2) * NW * XB + 256 + ((OP == SOP_FM && NW == 16) ? sizeof(float) * 10 * F : 0);
     if (lds > 64 * 1024) {
         static bool attr = false;
         if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spec_fused<OP, SRC_SPEC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
