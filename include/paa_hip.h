@@ -169,8 +169,9 @@ int paa_model_layout(const paa_model* m, int i);  /* padded rows of conv layer i
 struct paa_gemm_desc;
 paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
 /* Test / measurement aid: kernel selection of paa_gemm for the large regular products.  0 = automatic (default),
- * 1 = register-staged kernels only, 2.. = force one LDS-DMA ring configuration wherever its shape constraints hold
- * (csrc/gemm_ring.hip).  Results are bit-identical across configurations (same K order); tests assert that. */
+ * 1 = register-staged kernels only, 2..8 = force one LDS-DMA ring configuration wherever its shape constraints hold
+ * (csrc/gemm_ring.hip).  Results are bit-identical across configurations 0..8 (same K order); tests assert that.
+ * (9 / 10 exist only under PAA_MF16_PROBE=1: MFMA-shape timing probes whose results are wrong by construction.) */
 void paa_gemm_config(int ring_mode);
 /* Measurement aid (bench.py roofline leg): HIP-event timing of every GEMM launch on its own stream.
  * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[64][4] =

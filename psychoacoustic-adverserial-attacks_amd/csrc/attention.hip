@@ -56,7 +56,7 @@ __device__ __forceinline__ bf16x8 frag_rm(const unsigned short* rm, int lr, int 
 // A fragment of the TRANSPOSED tile for k-step s2, in the accumulator's k order, read from the row-major tile:
 // lane (lr, lh) gets column d = dt*32 + lr of rows 16 s2 + 4 lh + (0..3) [elements 0-3] and +8 [elements 4-7].
 // ds_read_b64_tr_b16: within a group of 16 lanes, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
-// 4 x 16 block, and lane i receives column i of the 4 rows (probed on the device: tools/scratch/tr_test.hip).
+// 4 x 16 block, and lane i receives column i of the 4 rows (probed on the device in round 1; the probe is in the git history under tools/scratch/).
 __device__ __forceinline__ bf16x8 frag_tr(const unsigned short* rm, int lr, int lh, int dt, int s2) {
     const int i = lr & 15;
     const unsigned short* p = rm + (16 * s2 + 4 * lh + (i >> 2)) * AT_RM + dt * 32 + (lr & 16) + 4 * (i & 3);

@@ -247,7 +247,7 @@ __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned s
 // Plain K-contiguous rows through a buffer resource that starts at the tile's first row and ends with the operand:
 // one 32-bit per-lane byte offset for the whole product, everything else scalar; rows past the operand's end
 // (last M / N tile) read zeros from the hardware bounds check instead of branching (the check covers the SGPR
-// offset too: probed with tools/scratch/buf_test.hip).  K must be a multiple of the 64-wide K tile.
+// offset too: probed in round 1, git history: tools/scratch/buf_test.hip).  K must be a multiple of the 64-wide K tile.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const unsigned short* base, int64_t elems) {
     const int64_t bytes = elems > 0 ? 2 * elems : 0;
