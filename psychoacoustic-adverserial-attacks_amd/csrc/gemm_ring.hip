@@ -58,7 +58,7 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     constexpr int MI = BM / WR / 32, NJ = BN / WC / 32, KS = BK / 16;
     constexpr int D = NST - 1;                 // stages in flight ahead of the MFMAs
     static_assert(NJ == 2, "vector epilogue: 64 columns per wave");
-    static_assert(ROWS % (RPI * NW) == 0 && BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "a DMA round must not straddle operands");
+    static_assert(ROWS % (RPI * NW) == 0 && PROWS % RPI == 0 && BM % RPI == 0, "a DMA wave-instruction must not straddle operands or planes");
     static_assert(NST * STAGE <= 160 * 1024 && D >= 1 && D <= 3 && D * GPW < 64, "ring does not fit");
     static_assert(!AHEAD || D >= 2, "certifying one stage ahead needs two stages of lookahead");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
@@ -94,10 +94,10 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < GPW; ++i) {
             const int r = (i * NW + wave) * RPI + lane / CPR;             // ring row of this lane's chunk
-            const int pl = (i * NW * RPI) / PROWS;                         // plane and operand are compile-time per i
-            const int rr = r - pl * PROWS;
+            const int pl = r / PROWS;                                      // plane (0 = hi, 1 = lo)
+            const int rr = r - pl * PROWS;                                 // row inside the plane: A rows, then B rows
             const int ch = (lane % CPR) ^ ((r / RBR) & (CPR - 1));        // global chunk that lands in slot lane % CPR
-            if ((i * NW * RPI) % PROWS < BM) {
+            if (rr < BM) {
                 const unsigned short* A = reinterpret_cast<const unsigned short*>(pl ? d.A_lo : (const void*)d.A) + aoff;
                 src[i] = A + (int64_t)min(c.m0 + rr, d.M - 1) * d.lda + ch * 8;
             } else {
@@ -279,6 +279,8 @@ void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
         case 6: launch_ring<256, 128, 32, 1, 3, 4, 2, true>(g, st); break;      // split, 3 stages, certified one ahead
         case 7: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2>(g, st); break;  // split, 192-row tiles, 2 x 40 KB, two workgroups per CU
         case 8: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2>(g, st); break;  // bf16, 192-row tiles, 2 x 40 KB, two workgroups per CU
+        case 11: launch_ring<192, 128, 16, 1, 4, 2, 2, false, 2>(g, st); break; // split, 192-row tiles, 4 x 20 KB (K slabs of 16), three in flight, two per CU
+        case 12: launch_ring<192, 128, 32, 0, 4, 2, 2, false, 2>(g, st); break; // bf16, 192-row tiles, 4 x 20 KB (K slabs of 32), three in flight, two per CU
         case 9: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2, true>(g, st); break;    // PROBE (wrong results): cfg 7 with 16x16x32 MFMAs
         case 10: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2, true>(g, st); break;   // PROBE (wrong results): cfg 8 with 16x16x32 MFMAs
         default: break;
@@ -288,13 +290,13 @@ void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
 int ring_tile_rows(int cfg) { return (cfg >= 7) ? 192 : 256; }
 int ring_tile_cols(int cfg) { return (cfg == 4 || cfg >= 6) ? 128 : 256; }
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
-    if (cfg < 2 || cfg > 10) return false;
+    if (cfg < 2 || cfg > 12) return false;
     // 9 / 10 are timing probes with WRONG results (MF16): only reachable when the measurement script asks for them
     static const bool probes = getenv("PAA_MF16_PROBE") != nullptr;
-    if (cfg >= 9 && !probes) return false;
-    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9;
+    if ((cfg == 9 || cfg == 10) && !probes) return false;
+    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11;
     if (split != (d.precision != 0)) return false;
-    const int bk = (cfg == 2 || cfg == 8 || cfg == 10) ? 64 : 32;
+    const int bk = (cfg == 2 || cfg == 8 || cfg == 10) ? 64 : cfg == 11 ? 16 : 32;
     return d.K % bk == 0 && d.K >= 4 * bk;
 }
 
