@@ -267,29 +267,35 @@ __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rs, unsigned vof
 // PERM (B tile of the vector-epilogue kernels): tile row n of each 64-row group goes to LDS row
 // ((n >> 2) & 1) * 32 + (n >> 3) * 4 + (n & 3), so that lane lr of accumulator j multiplies column
 // 8 (lr >> 2) + 4 j + (lr & 3): after the quad transpose a lane owns 8 consecutive columns.
-template <int ROWS, int NT, bool PERM>
+// SWZ: unpadded 128-byte rows with the 16-byte chunk index XORed by (row >> 1) & 7 (every ds_read_b128 lane group and
+// every 8-lane ds_write_b128 group then covers distinct banks) instead of rows padded to 144 bytes: a 192 x 128 split tile
+// is then exactly 80 KB and two workgroups fit a CU.
+template <int ROWS, int NT, bool PERM, bool SWZ = false>
 __device__ __forceinline__ void store_bf(unsigned short* lds, const uint4 (&v)[ROWS * 8 / NT], int tid) {
+    constexpr int LD = SWZ ? 64 : H_LD;
 #pragma unroll
     for (int i = 0; i < ROWS * 8 / NT; ++i) {
         int r = (tid >> 3) + (NT / 8) * i;
         if (PERM) r = (r & ~63) | ((((r >> 2) & 1) << 5) + (((r & 63) >> 3) << 2) + (r & 3));
-        *reinterpret_cast<uint4*>(lds + r * H_LD + ((tid & 7) << 3)) = v[i];
+        const int ch = SWZ ? ((tid & 7) ^ ((r >> 1) & 7)) : (tid & 7);
+        *reinterpret_cast<uint4*>(lds + r * LD + (ch << 3)) = v[i];
     }
 }
 
 // WM x 2 waves; each wave owns a (BM / WM) x (BN / 2) sub-tile = MI x NJ accumulators of 32 x 32.
-template <int BM, int BN, int PREC, int WM, bool VEC, bool SEG>
+template <int BM, int BN, int PREC, int WM, bool VEC, bool SEG, bool SWZ = false>
 __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_gemm_bf(GemmArgs g) {
     constexpr int NT = WM * 128;
+    constexpr int LD = SWZ ? 64 : H_LD;                   // LDS row stride in bf16 elements
     constexpr int NPL = PREC ? 2 : 1;
     constexpr int NJ = BN / 64;
     constexpr int MI = BM / (32 * WM);
     static_assert(!VEC || NJ == 2, "vector epilogue needs 64 columns per wave");
-    __shared__ __attribute__((aligned(16))) unsigned short smem[NPL * (BM + BN) * H_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short smem[NPL * (BM + BN) * LD];
     unsigned short* sAh = smem;
-    unsigned short* sAl = smem + (PREC ? BM * H_LD : 0);
-    unsigned short* sBh = smem + NPL * BM * H_LD;
-    unsigned short* sBl = sBh + (PREC ? BN * H_LD : 0);
+    unsigned short* sAl = smem + (PREC ? BM * LD : 0);
+    unsigned short* sBh = smem + NPL * BM * LD;
+    unsigned short* sBl = sBh + (PREC ? BN * LD : 0);
 
     const paa_gemm_desc& d = g.d;
     const int nwg = g.tiles_m * g.tiles_n;
@@ -334,9 +340,9 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
         }
     };
     auto store_tile = [&](int tid) {
-        store_bf<BM, NT, false>(sAh, rah, tid);
-        store_bf<BN, NT, VEC>(sBh, rbh, tid);
-        if constexpr (PREC) { store_bf<BM, NT, false>(sAl, ral, tid); store_bf<BN, NT, VEC>(sBl, rbl, tid); }
+        store_bf<BM, NT, false, SWZ>(sAh, rah, tid);
+        store_bf<BN, NT, VEC, SWZ>(sBh, rbh, tid);
+        if constexpr (PREC) { store_bf<BM, NT, false, SWZ>(sAl, ral, tid); store_bf<BN, NT, VEC, SWZ>(sBl, rbl, tid); }
     };
 
     int t = blockIdx.x;
@@ -374,18 +380,22 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
             {
                 constexpr int KS = H_BK / 16;
                 constexpr int NM = NJ * (PREC ? 3 : 1);                  // MFMAs per (ks, i)
-                const unsigned short* pa = sAh + (wm * (32 * MI) + lr) * H_LD + lh * 8;
-                const unsigned short* pb = sBh + (wn * (BN / 2) + lr) * H_LD + lh * 8;
-                constexpr int LO_A = BM * H_LD, LO_B = BN * H_LD;        // hi -> lo plane distance (PREC only)
+                // k slice ks of the fragment row: 16-byte chunk 2 ks + lh, XOR-swizzled by the row in the unpadded layout
+                int offk[KS];
+#pragma unroll
+                for (int q = 0; q < KS; ++q) offk[q] = SWZ ? (((2 * q + lh) ^ ((lr >> 1) & 7)) << 3) : (lh * 8 + q * 16);
+                const unsigned short* pa = sAh + (wm * (32 * MI) + lr) * LD;
+                const unsigned short* pb = sBh + (wn * (BN / 2) + lr) * LD;
+                constexpr int LO_A = BM * LD, LO_B = BN * LD;            // hi -> lo plane distance (PREC only)
                 bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD);
-                    if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(pb + LO_B + j * 32 * H_LD);
+                    bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * LD + offk[0]);
+                    if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(pb + LO_B + j * 32 * LD + offk[0]);
                     bhn[j] = bh[j]; bln[j] = bl[j];
                 }
-                ah = *reinterpret_cast<const bf16x8*>(pa);
-                if (PREC) al = *reinterpret_cast<const bf16x8*>(pa + LO_A);
+                ah = *reinterpret_cast<const bf16x8*>(pa + offk[0]);
+                if (PREC) al = *reinterpret_cast<const bf16x8*>(pa + LO_A + offk[0]);
                 ahn = ah; aln = al;
                 __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
 #pragma unroll
@@ -394,13 +404,13 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
                     for (int i = 0; i < MI; ++i) {
                         const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
                         if (nks < KS) {
-                            ahn = *reinterpret_cast<const bf16x8*>(pa + ni * 32 * H_LD + nks * 16);
-                            if (PREC) aln = *reinterpret_cast<const bf16x8*>(pa + LO_A + ni * 32 * H_LD + nks * 16);
+                            ahn = *reinterpret_cast<const bf16x8*>(pa + ni * 32 * LD + offk[nks < KS ? nks : 0]);
+                            if (PREC) aln = *reinterpret_cast<const bf16x8*>(pa + LO_A + ni * 32 * LD + offk[nks < KS ? nks : 0]);
                             if (ni == 0) {
 #pragma unroll
                                 for (int j = 0; j < NJ; ++j) {
-                                    bhn[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * H_LD + nks * 16);
-                                    if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(pb + LO_B + j * 32 * H_LD + nks * 16);
+                                    bhn[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * LD + offk[nks < KS ? nks : 0]);
+                                    if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(pb + LO_B + j * 32 * LD + offk[nks < KS ? nks : 0]);
                                 }
                             }
                         }
@@ -583,12 +593,12 @@ static int resident_blocks(K kernel, int threads) {
     return cus * per;
 }
 
-template <int BM, int BN, int PREC, int WM, bool VEC, bool SEG>
+template <int BM, int BN, int PREC, int WM, bool VEC, bool SEG, bool SWZ = false>
 static void launch_bf(const GemmArgs& g, hipStream_t st) {
-    static const int resident = resident_blocks(k_gemm_bf<BM, BN, PREC, WM, VEC, SEG>, WM * 128);
+    static const int resident = resident_blocks(k_gemm_bf<BM, BN, PREC, WM, VEC, SEG, SWZ>, WM * 128);
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
-    hipLaunchKernelGGL((k_gemm_bf<BM, BN, PREC, WM, VEC, SEG>), dim3(blocks), dim3(WM * 128), 0, st, g);
+    hipLaunchKernelGGL((k_gemm_bf<BM, BN, PREC, WM, VEC, SEG, SWZ>), dim3(blocks), dim3(WM * 128), 0, st, g);
 }
 
 // gemm_ring.hip: LDS-DMA ring kernels (configuration ids: see launch_ring_cfg)
@@ -678,14 +688,19 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             const int64_t t192 = (int64_t)cdiv(d.M, 192) * cdiv(d.N, 128) * d.batch;
             const int64_t r192 = (t192 + 2 * slots - 1) / (2 * slots);             // rounds of 192 x 128 tiles, two per CU
             const double c256 = (double)r256 * 256.0, c192 = (double)r192 * 192.0 * 2.0;
-            ring = (c192 < 0.95 * c256) ? 7 : 0;      // the long conv products stay on the 256 x 128 kernel (3..8 % faster there since its GELU went branch-free)
+            // (13 = the register-staged 192 x 128 split tile with swizzled, unpadded LDS, two workgroups per CU — whole
+            // 128-byte rows per request — measures within +-3 % of the ring kernel product by product and identically on
+            // the whole step: 39.9 ms either way; kept as a selectable configuration.)
+            // The long conv products stay on the 256 x 128 kernel (3..8 % faster there since its GELU went branch-free).
+            ring = (c192 < 0.95 * c256) ? 7 : 0;
         } else if (bm192) {
             ring = 8;             // bf16: wherever 192-row tiles fill the grid better (N = 768 / 2304: +3..10 %)
         }
-        if (ring && !ring_cfg_ok(ring, d)) ring = 0;
+        if (ring == 13) { if (!d.precision) ring = 0; }          // 13: register-staged 192 x 128 split tile, swizzled LDS, two workgroups per CU
+        else if (ring && !ring_cfg_ok(ring, d)) ring = 0;
         (void)t256;
     }
-    const int ring_bn = ring ? ring_tile_cols(ring) : 0, ring_bm = ring ? ring_tile_rows(ring) : 0;
+    const int ring_bn = ring == 13 ? 128 : ring ? ring_tile_cols(ring) : 0, ring_bm = ring == 13 ? 192 : ring ? ring_tile_rows(ring) : 0;
     g.tiles_m = cdiv(d.M, ring ? ring_bm : tall ? (bm192 ? 192 : 256) : G_BM);
     g.tiles_n = cdiv(d.N, ring ? ring_bn : bn);
     dim3 grid(g.tiles_m * g.tiles_n, d.batch);
@@ -738,7 +753,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     }
     if (ring) {
         if (prof) g_prof.variant[g_prof.n] = d.precision ? 61 : 60;
-        launch_ring_cfg(ring, g, st);
+        if (ring == 13) launch_bf<192, 128, 1, 2, true, false, true>(g, st);
+        else launch_ring_cfg(ring, g, st);
     } else if (d.operand_bf16) {
         const bool seg = d.a_kseg > 0 || (d.K & 63);          // segmented / windowed A or a K tail: general loader
         if (narrow) {

@@ -209,7 +209,7 @@ def test_gemm_bf16_operands(prec):
              dict(A=(Mr + 8) * Co, B=Ci * 2 * Co, C=Mr * 2 * Ci, aux=Mr * 2 * Ci), prec, offs=dict(A=7 * Co, C=Ci, aux=Ci), x16=True)
 
 
-@pytest.mark.parametrize("prec,cfg", [(0, 2), (0, 3), (0, 5), (0, 8), (0, 12), (1, 4), (1, 6), (1, 7), (1, 11)])
+@pytest.mark.parametrize("prec,cfg", [(0, 2), (0, 3), (0, 5), (0, 8), (0, 12), (1, 4), (1, 6), (1, 7), (1, 11), (1, 13)])
 def test_gemm_ring_configurations(prec, cfg):
     """LDS-DMA ring kernels (csrc/gemm_ring.hip) forced through paa_gemm_config: vs the numpy statement of the descriptor
     and BIT-identical to the register-staged kernel (cfg 1) on the same buffers — M / N edges inside the last tiles, a
