@@ -2,6 +2,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "gemm_dev.h"
 
@@ -19,6 +20,11 @@ namespace paa {
 // fragment reads apply the same XOR (f = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows: every
 // ds_read_b128 lane group then covers all 64 banks).  B rows are permuted inside each 64-row group exactly as
 // store_bf<PERM> does, for the vector epilogue.  Stage layout: A_hi rows | B_hi rows [| A_lo rows | B_lo rows].
+#ifdef PAA_CLOCK_STAMP
+// Diagnostic build only (tools/clock_probe.py): shader-clock ticks and 100 MHz real-time ticks around each workgroup's
+// whole tile loop, written to a buffer of their own that nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ unsigned long long g_clock_stamp[2 * 1024];
+#endif
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 template <int N>
@@ -133,6 +139,9 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     const int arow = (wr * (BM / WR) + lr) * RB, brow = (BM + wc * (BN / WC) + lr) * RB;
     constexpr int LO = PROWS * RB;             // hi -> lo plane distance inside a stage
 
+#ifdef PAA_CLOCK_STAMP
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int cslot = 0;                             // slot of the stage the MFMAs consume next
     constexpr int NM = NJ * (PREC ? 3 : 1);
     bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
@@ -250,6 +259,12 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
         }
         epilogue_vec<MI, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
     }
+#ifdef PAA_CLOCK_STAMP
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_clock_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_t0;
+        g_clock_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
+#endif
 }
 
 // resident workgroups of a kernel on this device (CUs x occupancy)
@@ -286,6 +301,23 @@ void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
         default: break;
     }
 }
+
+#ifdef PAA_CLOCK_STAMP
+}  // namespace paa
+// median over workgroups of (shader ticks / 100 MHz ticks) * 0.1 = GHz held during the last ring-kernel launch
+extern "C" double paa_debug_ring_clock_ghz(int n_blocks) {
+    static unsigned long long host[2 * 1024];
+    if (n_blocks > 1024) n_blocks = 1024;
+    if (hipDeviceSynchronize() != hipSuccess) return -1.0;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(paa::g_clock_stamp), sizeof(unsigned long long) * 2 * n_blocks) != hipSuccess) return -2.0;
+    std::vector<double> r;
+    for (int i = 0; i < n_blocks; ++i) if (host[2 * i + 1] > 0) r.push_back(0.1 * (double)host[2 * i] / (double)host[2 * i + 1]);
+    if (r.empty()) return 0.0;
+    std::sort(r.begin(), r.end());
+    return r[r.size() / 2];
+}
+namespace paa {
+#endif
 
 int ring_tile_rows(int cfg) { return (cfg >= 7) ? 192 : 256; }
 int ring_tile_cols(int cfg) { return (cfg == 4 || cfg >= 6) ? 128 : 256; }
