@@ -1,4 +1,5 @@
-// conv0 GroupNorm backward, bf16 mode: ONE pass over the gradient dy (B, P, C) for both things the backward needs.
+// conv0 GroupNorm backward: ONE pass over the gradient dy (B, P, C) for both things the backward needs (both precision
+// modes since round 2: PREC = 1 carries dy and W1 as hi + lo bf16 planes and every product as three MFMA passes).
 //
 // The gradient wrt the conv0 GroupNorm output is the largest tensor of the backward pass (32 x 31999 x 512 bf16 = 1 GB
 // at the benchmark size) and it used to be read twice: by the channel statistics kernel (s1 = mean_t dy,
@@ -31,8 +32,10 @@ int conv0_dgrad_blocks(int B, int T) {
     return std::max(1, std::min(std::min(512 / std::max(B, 1), 64), ntiles));
 }
 
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[DG_T * DG_RS];
+    constexpr int NPL = PREC ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[NPL * DG_T * DG_RS];          // hi rows, then lo rows
     __shared__ __attribute__((aligned(16))) float red[4][DG_T * 16];
     __shared__ float xs[(DG_T - 1) * 5 + 10 + 1];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -41,8 +44,12 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
     const int nchunks = DG_T * cpr;
     const int ntiles = (a.T + DG_T - 1) / DG_T;
     const unsigned short* __restrict__ dy = a.dpreb.hi + (size_t)b * a.P * C;
+    const unsigned short* __restrict__ dyl = PREC ? a.dpreb.lo + (size_t)b * a.P * C : nullptr;
+    constexpr int LO = DG_T * DG_RS;           // hi -> lo tile distance in LDS
 
     // W1_b fragments of this wave's k-steps (k-step ks = w + 4 i): column j = lr, elements 16 ks + 8 lh ..
+    // (PREC: the lo fragments are re-read per tile — 8 L1-resident 16-byte loads — rather than held: holding both planes
+    // next to the 64 accumulators and the two register-staged tiles does not fit 256 VGPRs)
     bf16x8 wf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -57,6 +64,8 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[i][e] = 0.f;
 
+    // (PREC: only the hi plane is register-staged across the compute phase; the lo plane is loaded inside stage(), its
+    // latency covered by the other workgroup of the CU — both planes in registers spill)
     uint4 st[8];
     auto fetch = [&](int t0) {            // tile rows -> registers (rows >= T read as zero: pad rows may hold anything)
 #pragma unroll
@@ -74,6 +83,26 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
             const int idx = tid + 256 * v;
             const int row = idx / cpr, col = idx - row * cpr;
             if (idx < nchunks) *reinterpret_cast<uint4*>(tile + row * DG_RS + 8 * col) = st[v];
+        }
+        if (PREC) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 stl[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int idx = tid + 256 * (4 * h + v);
+                    const int row = idx / cpr, col = idx - row * cpr;
+                    uint4 zl = make_uint4(0u, 0u, 0u, 0u);
+                    if (idx < nchunks && t0 + row < a.T) zl = *reinterpret_cast<const uint4*>(dyl + (size_t)(t0 + row) * C + 8 * col);
+                    stl[v] = zl;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int idx = tid + 256 * (4 * h + v);
+                    const int row = idx / cpr, col = idx - row * cpr;
+                    if (idx < nchunks) *reinterpret_cast<uint4*>(tile + LO + row * DG_RS + 8 * col) = stl[v];
+                }
+            }
         }
         if (tid < (DG_T - 1) * 5 + 10) {
             const int i = t0 * 5 + tid;
@@ -93,11 +122,20 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
         f32x16 g;
 #pragma unroll
         for (int e = 0; e < 16; ++e) g[e] = 0.f;
+        const unsigned short* wlo = PREC ? a.w1b.lo + ((size_t)b * 16 + (lr & 15)) * C + 8 * lh : nullptr;
+        if (PREC) asm volatile("" : "+v"(wlo));          // opaque per tile: keeps these loads inside the loop
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ks = w + 4 * i;
             if (ks < nks) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(tile + lr * DG_RS + 16 * ks + 8 * lh);
+                if (PREC) {
+                    const bf16x8 afl = *reinterpret_cast<const bf16x8*>(tile + LO + lr * DG_RS + 16 * ks + 8 * lh);
+                    bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlo + 16 * ks);
+                    if (lr >= 16) wl = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl, wf[i], g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wl, g, 0, 0, 0);
+                }
                 g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[i], g, 0, 0, 0);
             }
         }
@@ -128,6 +166,13 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
                     const bf16x4 u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + 8 * DG_RS));
                     bf16x8 af;
                     af[0] = u0[0]; af[1] = u0[1]; af[2] = u0[2]; af[3] = u0[3]; af[4] = u1[0]; af[5] = u1[1]; af[6] = u1[2]; af[7] = u1[3];
+                    if (PREC) {
+                        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + LO));
+                        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + LO + 8 * DG_RS));
+                        bf16x8 afl;
+                        afl[0] = v0[0]; afl[1] = v0[1]; afl[2] = v0[2]; afl[3] = v0[3]; afl[4] = v1[0]; afl[5] = v1[1]; afl[6] = v1[2]; afl[7] = v1[3];
+                        sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl, xh[s], sacc[i], 0, 0, 0);
+                    }
                     sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xh[s], sacc[i], 0, 0, 0);
                     sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xl[s], sacc[i], 0, 0, 0);
                 }
@@ -185,7 +230,7 @@ __global__ __launch_bounds__(256) void k_conv0_s_finalize(Conv0Args a, int nblk)
 }
 
 bool conv0_dgrad_supported(const Conv0Args& a) {
-    return !a.dpreb.lo && !a.w1b.lo && a.stride == 5 && a.k == 10 && (a.C & 31) == 0 && a.C <= DG_CMAX && a.C >= 32;
+    return (a.dpreb.lo != nullptr) == (a.w1b.lo != nullptr) && a.stride == 5 && a.k == 10 && (a.C & 31) == 0 && a.C <= DG_CMAX && a.C >= 32;
 }
 
 int64_t conv0_dgrad_part_floats(int B, int T, int C) { return (int64_t)B * conv0_dgrad_blocks(B, T) * C * 16; }
@@ -196,7 +241,11 @@ paa_status conv0_dgrad_fused(const Conv0Args& a, float* part, hipStream_t st) {
     Conv0Args b = a;
     b.part = part;
     const int nblk = conv0_dgrad_blocks(a.B, a.T);
-    hipLaunchKernelGGL(k_conv0_dgrad, dim3(nblk, a.B), dim3(256), 0, st, b);
+    if (a.dpreb.lo) {
+        hipLaunchKernelGGL(k_conv0_dgrad<1>, dim3(nblk, a.B), dim3(256), 0, st, b);
+    } else {
+        hipLaunchKernelGGL(k_conv0_dgrad<0>, dim3(nblk, a.B), dim3(256), 0, st, b);
+    }
     PAA_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_conv0_s_finalize, dim3(cdiv((int64_t)a.B * a.C, 256)), dim3(256), 0, st, b, nblk);
     PAA_LAUNCH_CHECK();

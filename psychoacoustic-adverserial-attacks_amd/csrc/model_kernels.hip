@@ -717,8 +717,8 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
     }
     // PAA_CONV0_TWO_PASS=1 (tests): keep the statistics pass + GEMM pass also in bf16 mode, to compare the two paths
     const char* two_pass = getenv("PAA_CONV0_TWO_PASS");
-    if (!precision && conv0_dgrad_supported(a) && !(two_pass && two_pass[0] == '1')) {
-        // bf16 mode: W1_b first (forward statistics only), then ONE pass over dy for G1 and the GroupNorm sums
+    if (conv0_dgrad_supported(a) && !(two_pass && two_pass[0] == '1')) {
+        // W1_b first (forward statistics only), then ONE pass over dy for G1 and the GroupNorm sums (both precision modes)
         hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a, 1);
         PAA_LAUNCH_CHECK();
         PAA_TRY(conv0_dgrad_fused(a, part, st));
