@@ -67,6 +67,13 @@ typedef struct paa_gemm_desc {
     // C_pre[m,n] = gelu'(v), act GELU_GRAD multiplies by aux[m,n] as it stands.  The derivative is evaluated once, next
     // to the GELU that shares its exp, instead of again in every backward epilogue (bf16 mode, together with aux_bf16).
     int32_t aux_gate;
+    // k_group > 0 (operand_bf16 products whose A rows are OVERLAPPING windows: strided convolutions, K = taps * k_group,
+    // lda < K): the K slabs are walked channel-slab-major, tap-minor — slab (c, tap) = elements tap * k_group + c * BK ..
+    // — instead of 0 .. K in order.  Consecutive output rows share input frames between taps (row r's tap 2 is row
+    // r + 1's tap 0 at stride 2); in K order those two uses of one cache line are k_group / BK slabs apart and the line has
+    // left L2 by then, tap-minor they are adjacent slabs.  Same products, different f32 summation order; ignored when
+    // k_group is not a multiple of the kernel's K slab.
+    int32_t k_group;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

@@ -301,6 +301,9 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     const int nwg = g.tiles_m * g.tiles_n;
     const int total = nwg * d.batch;
     const int nk = (d.K + H_BK - 1) / H_BK;
+    // k_group order of the K tiles (gemm.h): kg_spt slabs per tap, kg_taps taps; 0 = plain K order
+    const int kg_spt = (d.k_group > 0 && d.k_group % H_BK == 0 && d.K % d.k_group == 0 && d.K > d.k_group) ? d.k_group / H_BK : 0;
+    const int kg_taps = kg_spt ? d.K / d.k_group : 1;
 
     // tile t -> (batch z, row m0, column n0).  XCD-aware order inside a batch entry: workgroups that share
     // (id % 8) — one XCD's L2 — walk a contiguous run of tiles, A row-panel major (bijective for any tile count).
@@ -369,10 +372,16 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+        int ktap = 0, kc = 0;                                  // (tap, channel slab) of K tile kt in the k_group order
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();                                   // K tile kt is in LDS
             const bool last = kt + 1 == nk;
-            if (!last) load_tile(cur, (kt + 1) * H_BK, tid);
+            int knext = kt + 1;
+            if (kg_spt) {
+                if (++ktap == kg_taps) { ktap = 0; ++kc; }
+                knext = ktap * kg_spt + kc;
+            }
+            if (!last) load_tile(cur, knext * H_BK, tid);
             else if (more) load_tile(nxt, 0, tid);
             // Fragment reads run one MFMA group ahead of their use: while the MFMAs of (ks, i) issue, the A fragment
             // of the next (ks, i) — and at the end of a ks step the B fragments of the next one — are already on their
@@ -681,24 +690,39 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         // two workgroups per CU win wherever 256-row tiles leave the persistent grid's last round part-empty (N = 768:
         // 378 tiles on 256 slots, +15..22 % split, +5..10 % bf16; N = 2304: +3..10 %); everywhere else the ring kernels
         // only tie the register-staged ones (within 3 %), which stay the default.
+        const char* nsq = getenv("PAA_NO_SQ");           // A/B measurements (read per call): automatic selection without the 256 x 256 rings
+        const bool no_sq = nsq && nsq[0] == '1';
         if (g_ring_mode >= 2) ring = g_ring_mode;
         else if (d.precision) {
             const int64_t slots = 256;
             const int64_t r256 = (t128 + slots - 1) / slots;                       // rounds of 256 x 128 tiles, one workgroup per CU
             const int64_t t192 = (int64_t)cdiv(d.M, 192) * cdiv(d.N, 128) * d.batch;
             const int64_t r192 = (t192 + 2 * slots - 1) / (2 * slots);             // rounds of 192 x 128 tiles, two per CU
-            const double c256 = (double)r256 * 256.0, c192 = (double)r192 * 192.0 * 2.0;
+            const int64_t rsq = (t256 + slots - 1) / slots;                        // rounds of 256 x 256 tiles, one per CU
+            // cost = rounds x per-CU work of a round (in 128-column units), divided by the per-flop efficiency each
+            // kernel measured against the register-staged 256 x 128 one (tools/gemm_ring_bench.py, profiles/r2_gemm_ab_sq.txt):
+            // the 256 x 256 ring (17: eight waves, 2 x 64 KB) is 8..10 % faster per flop — conv stack, N = 3072 — and
+            // fetches each A panel for 2 column tiles instead of 4; the 192 x 128 ring (7) wins where its tiles fill the
+            // last round (N = 768 / 2304 at M = 16000).
             // (13 = the register-staged 192 x 128 split tile with swizzled, unpadded LDS, two workgroups per CU — whole
-            // 128-byte rows per request — measures within +-3 % of the ring kernel product by product and identically on
-            // the whole step: 39.9 ms either way; kept as a selectable configuration.)
-            // The long conv products stay on the 256 x 128 kernel (3..8 % faster there since its GELU went branch-free).
-            ring = (c192 < 0.95 * c256) ? 7 : 0;
+            // 128-byte rows per request — measures within +-3 % of ring 7 product by product and identically on the whole
+            // step; kept as a selectable configuration.)
+            const double c256 = (double)r256 * 256.0, c192 = (double)r192 * 192.0 * 2.0 / 0.95, csq = (double)rsq * 512.0 / 1.08;
+            ring = 0;
+            double best = c256;
+            if (c192 < best) { best = c192; ring = 7; }
+            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(17, d) && csq < best) { best = csq; ring = 17; }
         } else if (bm192) {
             ring = 8;             // bf16: wherever 192-row tiles fill the grid better (N = 768 / 2304: +3..10 %)
+        } else if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(2, d)) {
+            // bf16, 256 x 256 ring (2): ties the register-staged 256 x 128 kernel on time (within 3 %) where its tiles
+            // fill the grid equally well, and halves the A-panel fetches from the fabric (profiles/r2_kgroup_pmc.txt)
+            static const int slots2 = std::max(1, resident_blocks(k_gemm_bf<256, 128, 0, 2, true, false>, 256));
+            const int64_t r2 = (t128 + slots2 - 1) / slots2, rsq = (t256 + 255) / 256;
+            if (rsq <= r2) ring = 2;      // a round is one 256 x 256 tile or two co-resident 256 x 128 tiles per CU: equal work
         }
         if (ring == 13) { if (!d.precision) ring = 0; }          // 13: register-staged 192 x 128 split tile, swizzled LDS, two workgroups per CU
         else if (ring && !ring_cfg_ok(ring, d)) ring = 0;
-        (void)t256;
     }
     const int ring_bn = ring == 13 ? 128 : ring ? ring_tile_cols(ring) : 0, ring_bm = ring == 13 ? 192 : ring ? ring_tile_rows(ring) : 0;
     g.tiles_m = cdiv(d.M, ring ? ring_bm : tall ? (bm192 ? 192 : 256) : G_BM);

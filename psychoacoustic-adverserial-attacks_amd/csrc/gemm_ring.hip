@@ -63,7 +63,7 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     constexpr int GPW = ROWS / RPI / NW;       // DMA wave-instructions per wave per stage
     constexpr int MI = BM / WR / 32, NJ = BN / WC / 32, KS = BK / 16;
     constexpr int D = NST - 1;                 // stages in flight ahead of the MFMAs
-    static_assert(NJ == 2, "vector epilogue: 64 columns per wave");
+    static_assert(NJ == 2 || NJ == 4, "vector epilogue: 64-column groups per wave");
     static_assert(ROWS % (RPI * NW) == 0 && PROWS % RPI == 0 && BM % RPI == 0, "a DMA wave-instruction must not straddle operands or planes");
     static_assert(NST * STAGE <= 160 * 1024 && D >= 1 && D <= 3 && D * GPW < 64, "ring does not fit");
     static_assert(!AHEAD || D >= 2, "certifying one stage ahead needs two stages of lookahead");
@@ -93,6 +93,10 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     // ---- load cursor: (tile lt, K slab lk) is the next stage to request --------------------------------------------
     int lt = blockIdx.x, lk = 0;
     if (lt >= total) return;
+    // k_group order of the K slabs (gemm.h): kg_spt slabs per tap, kg_taps taps; 0 = plain K order
+    const int kg_spt = (d.k_group > 0 && d.k_group % BK == 0 && d.K % d.k_group == 0 && d.K > d.k_group) ? d.k_group / BK : 0;
+    const int kg_taps = kg_spt ? d.K / d.k_group : 1;
+    int ltap = 0, lc = 0, lslab = 0;           // (tap, channel slab) and K slab index of the next stage to request
     const unsigned short* src[GPW];
     auto set_src = [&](int t) {
         const Tile c = decode(t);
@@ -118,9 +122,15 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
         unsigned char* st = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < GPW; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lk * BK), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lslab * BK), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
+        if (kg_spt) {
+            if (++ltap == kg_taps) { ltap = 0; ++lc; }
+            lslab = ltap * kg_spt + lc;
+        } else {
+            ++lslab;
+        }
         if (++lk == nk) {
-            lk = 0;
+            lk = 0; ltap = 0; lc = 0; lslab = 0;
             lt += gridDim.x;
             if (lt < total) set_src(lt);
         }
@@ -166,13 +176,15 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     bool first_it = true;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const Tile cur = decode(t);
-        f32x16 acc[MI][NJ];
+        f32x16 acc[NJ / 2][MI][2];             // [64-column group][row block][column block]: one epilogue_vec per group
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int h = 0; h < NJ / 2; ++h)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
 
         for (int kt = 0; kt < nk; ++kt) {
             if constexpr (AHEAD) {
@@ -235,10 +247,10 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         if (PREC) {
-                            mfma_step<MF16>(al, bh[j], acc[i][j]);
-                            mfma_step<MF16>(ah, bl[j], acc[i][j]);
+                            mfma_step<MF16>(al, bh[j], acc[j >> 1][i][j & 1]);
+                            mfma_step<MF16>(ah, bl[j], acc[j >> 1][i][j & 1]);
                         }
-                        mfma_step<MF16>(ah, bh[j], acc[i][j]);
+                        mfma_step<MF16>(ah, bh[j], acc[j >> 1][i][j & 1]);
                     }
                     __builtin_amdgcn_s_setprio(0);
                     if (nks < KS) {
@@ -257,7 +269,9 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
                     }
                 }
         }
-        epilogue_vec<MI, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
+        epilogue_vec<MI, true>(d, acc[0], cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
+        if constexpr (NJ == 4)      // (written out: a loop over the groups is not unrolled and sends the accumulators through scratch)
+            epilogue_vec<MI, true>(d, acc[1], cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC) + 64, cur.z1, cur.z2, lane);
     }
 #ifdef PAA_CLOCK_STAMP
     if (tid == 0 && blockIdx.x < 1024) {
@@ -296,6 +310,10 @@ void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
         case 8: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2>(g, st); break;  // bf16, 192-row tiles, 2 x 40 KB, two workgroups per CU
         case 11: launch_ring<192, 128, 16, 1, 4, 2, 2, false, 2>(g, st); break; // split, 192-row tiles, 4 x 20 KB (K slabs of 16), three in flight, two per CU
         case 12: launch_ring<192, 128, 32, 0, 4, 2, 2, false, 2>(g, st); break; // bf16, 192-row tiles, 4 x 20 KB (K slabs of 32), three in flight, two per CU
+        case 14: launch_ring<256, 256, 64, 0, 2, 2, 2, false, 1>(g, st); break; // bf16, FOUR waves of 128 x 128 (one per SIMD, 512-register budget), 2 x 64 KB
+        case 15: launch_ring<256, 256, 32, 0, 4, 2, 2, true, 1>(g, st); break;  // bf16, four waves of 128 x 128, 4 x 32 KB, certified one ahead
+        case 16: launch_ring<256, 256, 32, 1, 2, 2, 2, false, 1>(g, st); break; // split, four waves of 128 x 128, 2 x 64 KB
+        case 17: launch_ring<256, 256, 32, 1, 2, 2, 4, false>(g, st); break;    // split, 256 x 256, eight waves, 2 x 64 KB: the A panel is shared by 2 column tiles instead of 4
         case 9: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2, true>(g, st); break;    // PROBE (wrong results): cfg 7 with 16x16x32 MFMAs
         case 10: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2, true>(g, st); break;   // PROBE (wrong results): cfg 8 with 16x16x32 MFMAs
         default: break;
@@ -319,16 +337,16 @@ extern "C" double paa_debug_ring_clock_ghz(int n_blocks) {
 namespace paa {
 #endif
 
-int ring_tile_rows(int cfg) { return (cfg >= 7) ? 192 : 256; }
-int ring_tile_cols(int cfg) { return (cfg == 4 || cfg >= 6) ? 128 : 256; }
+int ring_tile_rows(int cfg) { return (cfg >= 7 && cfg <= 13) ? 192 : 256; }
+int ring_tile_cols(int cfg) { return (cfg == 4 || (cfg >= 6 && cfg <= 13)) ? 128 : 256; }
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
-    if (cfg < 2 || cfg > 12) return false;
+    if (cfg < 2 || cfg > 17 || cfg == 13) return false;
     // 9 / 10 are timing probes with WRONG results (MF16): only reachable when the measurement script asks for them
     static const bool probes = getenv("PAA_MF16_PROBE") != nullptr;
     if ((cfg == 9 || cfg == 10) && !probes) return false;
-    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11;
+    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16 || cfg == 17;
     if (split != (d.precision != 0)) return false;
-    const int bk = (cfg == 2 || cfg == 8 || cfg == 10) ? 64 : cfg == 11 ? 16 : 32;
+    const int bk = (cfg == 2 || cfg == 8 || cfg == 10 || cfg == 14) ? 64 : cfg == 11 ? 16 : 32;
     return d.K % bk == 0 && d.K >= 4 * bk;
 }
 

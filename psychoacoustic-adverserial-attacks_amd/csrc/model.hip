@@ -322,6 +322,8 @@ static paa_gemm_desc gd(const paa_model* m, const float* A, const float* Bm, flo
     d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;
     return d;
 }
+// PAA_K_GROUP=0 (A/B measurements, read per call): plain K order in the strided-conv products instead of gemm.h's k_group order
+static bool kgroup_on() { const char* e = getenv("PAA_K_GROUP"); return !(e && e[0] == '0'); }
 // bf16-operand descriptor (every conv / linear product)
 static paa_gemm_desc gdb(const paa_model* m, CBf A, CBf W, float* C, Bf Cb, int M, int N, int K, int64_t lda, int64_t ldb,
                          int64_t ldc) {
@@ -363,6 +365,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         const int K = c.k * c.cin;
         const bool last = i == nc - 1;
         paa_gemm_desc d = gdb(m, ro(pr.actb), c.w, nullptr, NOBF, B * c.P, c.cout, K, (int64_t)c.s * c.cin, K, c.cout);
+        d.k_group = kgroup_on() ? c.cin : 0;
         d.bias = c.b; d.row_period = c.P; d.row_valid = c.T;
         if (a.feat_norm_layer) {
             d.C = c.cv;
@@ -575,6 +578,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             }
             const int K = (Q + 1) * c.cout;
             paa_gemm_desc d = gdb(m, ro(m->gH[ji]).off(-(int64_t)Q * c.cout), c.wd[rho], nullptr, NOBF, B * c.P, c.cin, K, c.cout, K, ldo);
+            d.k_group = kgroup_on() ? c.cout : 0;
             if (out_f32) d.C = m->gF[jo] + (int64_t)rho * c.cin;
             else { Bf o = boff(m->gH[jo], (int64_t)rho * c.cin); d.Cb = o.hi; d.Cb_lo = o.lo; }
             d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_gate = d.aux_bf16;

@@ -209,7 +209,8 @@ def test_gemm_bf16_operands(prec):
              dict(A=(Mr + 8) * Co, B=Ci * 2 * Co, C=Mr * 2 * Ci, aux=Mr * 2 * Ci), prec, offs=dict(A=7 * Co, C=Ci, aux=Ci), x16=True)
 
 
-@pytest.mark.parametrize("prec,cfg", [(0, 2), (0, 3), (0, 5), (0, 8), (0, 12), (1, 4), (1, 6), (1, 7), (1, 11), (1, 13)])
+@pytest.mark.parametrize("prec,cfg", [(0, 2), (0, 3), (0, 5), (0, 8), (0, 12), (0, 14), (0, 15), (1, 4), (1, 6), (1, 7), (1, 11), (1, 13),
+                                      (1, 16), (1, 17)])
 def test_gemm_ring_configurations(prec, cfg):
     """LDS-DMA ring kernels (csrc/gemm_ring.hip) forced through paa_gemm_config: vs the numpy statement of the descriptor
     and BIT-identical to the register-staged kernel (cfg 1) on the same buffers — M / N edges inside the last tiles, a
@@ -230,6 +231,22 @@ def test_gemm_ring_configurations(prec, cfg):
                 outs[c] = _bf_case(f"{name}/cfg{c}", d, shapes, prec, seed=7, **kw)
             for k in outs[1]:
                 assert torch.equal(outs[1][k], outs[cfg][k]), (name, k, "ring result differs from the register-staged kernel")
+    finally:
+        L.paa_gemm_config(0)
+
+
+@pytest.mark.parametrize("prec,cfg", [(0, 1), (0, 2), (0, 8), (1, 1), (1, 7), (1, 17)])
+def test_gemm_k_group_order(prec, cfg):
+    """gemm.h k_group: the K slabs of a strided-conv product walked channel-slab-major / tap-minor (3 taps of 128 channels at
+    stride 2 here, and the 2-tap window of a stride-2 dgrad) — same products in another f32 summation order, so the
+    result is checked against the numpy statement at the usual tolerance, not bit for bit."""
+    L = _lib.lib()
+    try:
+        L.paa_gemm_config(cfg)
+        _bf_case(f"kgroup_fwd/cfg{cfg}", dict(M=4000, N=512, K=384, lda=256, ldb=384, ldc=512, row_period=500, row_valid=499, act=1, k_group=128),
+                 dict(A=(2 * 4000 + 8) * 128, B=512 * 384, C=4000 * 512, bias=512, C_pre=4000 * 512), prec, seed=11)
+        _bf_case(f"kgroup_dgrad/cfg{cfg}", dict(M=4000, N=512, K=512, lda=256, ldb=512, ldc=512, act=2, ld_aux=512, k_group=256),
+                 dict(A=(4000 + 8) * 256, B=512 * 512, C=4000 * 512, aux=4000 * 512), prec, seed=12)
     finally:
         L.paa_gemm_config(0)
 

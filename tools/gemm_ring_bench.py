@@ -15,14 +15,16 @@ L = _lib.lib()
 PROBES = [("probe conv1 bf16-out", 512000, 512, 1536, 1024, "bf"), ("probe conv1 bf16-out ALIASED rows", 512000, 512, 1536, 0, "bf"),
           ("probe ffn1 bf16-out", 16000, 3072, 768, None, "bf"), ("probe ffn1 bf16-out ALIASED rows", 16000, 3072, 768, 0, "bf"),
           ("probe sq8192 bf16-out", 8192, 8192, 8192, None, "bf")]
-SHAPES = [("conv1 fwd gelu", 512000, 512, 1536, 1024, "gelu"), ("conv1 dgrad even", 512000, 512, 1024, 512, "gg"),
+# " kg" in the name: gemm.h's k_group order of the K slabs (channel-slab-major, tap-minor), k_group = 512
+SHAPES = [("conv1 fwd gelu", 512000, 512, 1536, 1024, "gelu"), ("conv1 fwd gelu kg", 512000, 512, 1536, 1024, "gelu"),
+          ("conv1 dgrad even", 512000, 512, 1024, 512, "gg"), ("conv1 dgrad even kg", 512000, 512, 1024, 512, "gg"),
           ("conv2 fwd gelu", 256000, 512, 1536, 1024, "gelu"), ("conv4 fwd gelu", 64000, 512, 1536, 1024, "gelu"),
           ("ffn1 gelu", 16000, 3072, 768, None, "gelu"), ("ffn2 resid", 16000, 768, 3072, None, "res"),
           ("qkv", 16000, 2304, 768, None, "bf"), ("dffn (w2_t) gg", 16000, 3072, 768, None, "gg"),
           ("dqkv (wqkv_t) resid", 16000, 768, 2304, None, "res"), ("outproj resid", 16000, 768, 768, None, "res")]
 
 
-def build(M, N, K, lda, ep, prec):
+def build(M, N, K, lda, ep, prec, kg=0):
     alias = lda == 0              # every A / B row aliases row 0: operands always hit in cache (memory-system probe)
     lda = K if (lda is None or alias) else lda
     def rnd16(n, scale=1.0):          # random bf16 bit patterns of N(0, scale^2) values (full-range mantissas and signs)
@@ -39,6 +41,7 @@ def build(M, N, K, lda, ep, prec):
     d.alpha = 0.03
     d.operand_bf16 = 1
     d.precision = prec
+    d.k_group = kg
     keep = [A, B, Al, Bl, aux, aux16]
     outs = {}
 
@@ -85,20 +88,22 @@ def timeit(d, iters):
 
 
 def main():
-    cfgs = {0: [1, 8, 10], 1: [1, 7, 9]} if os.environ.get('PAA_MF16_PROBE') else {0: [1, 8], 1: [1, 7, 13]} if os.environ.get('PAA_DEEP_PROBE') else {0: [1, 2, 3, 5, 8], 1: [1, 4, 6, 7]}
+    cfgs = {0: [1, 2, 14, 15], 1: [1, 7, 16]} if os.environ.get('PAA_W4_PROBE') else {0: [1, 2, 8], 1: [1, 4, 17]} if os.environ.get('PAA_KG_PROBE') else {0: [1, 8, 10], 1: [1, 7, 9]} if os.environ.get('PAA_MF16_PROBE') else {0: [1, 8], 1: [1, 7, 13]} if os.environ.get('PAA_DEEP_PROBE') else {0: [1, 2, 3, 5, 8], 1: [1, 4, 6, 7]}
     argv = sys.argv[1:]
     pick = None
     if "--one" in argv:               # e.g. --one conv1  (profiling runs: one shape family, few launches)
         pick = argv[argv.index("--one") + 1]
         argv = [a for a in argv if a not in ("--one", pick)]
+    exact = "--exact" in argv         # --one matches the whole shape name
+    argv = [a for a in argv if a != "--exact"]
     only = [int(a) for a in argv]
     for prec in (0, 1):
         if only and prec not in only:
             continue
         for (nm, M, N, K, lda, ep) in (PROBES if pick == "probe" else SHAPES):
-            if pick and not nm.startswith(pick):
+            if pick and not (nm == pick if exact else nm.startswith(pick)):
                 continue
-            d, outs, keep = build(M, N, K, lda, ep, prec)
+            d, outs, keep = build(M, N, K, lda, ep, prec, 512 if nm.endswith(" kg") else 0)
             iters = 3 if M > 100000 else 10
             ref = None
             best = {}

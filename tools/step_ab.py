@@ -16,6 +16,10 @@ from paa_amd.training_utils import build, parser
 from paa_amd.training_utils.pgd import PgdStepper
 
 
+# auto = automatic selection, reg = register-staged kernels only; nosq = without the 256 x 256 rings; nokg = plain K order in the convs
+VARIANTS = ("auto", "auto nokg", "auto nosq", "auto nosq nokg", "reg", "reg nokg")
+
+
 def main(steps=15, rounds=3):
     lib = _lib.lib()
     a, B, L = A.BASE, 32, 160000
@@ -30,8 +34,10 @@ def main(steps=15, rounds=3):
         p = (torch.from_numpy(synth.perturbation(L, seed=5)) * np.float32(2e-3)).cuda()
         best = {}
         for rnd in range(rounds + 1):
-            for cfg in (0, 1):
-                lib.paa_gemm_config(cfg)
+            for cfg in VARIANTS:
+                os.environ["PAA_K_GROUP"] = "0" if "nokg" in cfg else "1"
+                os.environ["PAA_NO_SQ"] = "1" if "nosq" in cfg else "0"
+                lib.paa_gemm_config(1 if "reg" in cfg else 0)
                 for _ in range(2):
                     st.step(p, clean, labels, want_logits=False)
                 torch.cuda.synchronize()
@@ -43,7 +49,7 @@ def main(steps=15, rounds=3):
                 if rnd:
                     best.setdefault(cfg, []).append(ms)
         lib.paa_gemm_config(0)
-        print(dtype, {("auto (ring where selected)" if c == 0 else "register-staged only"): [round(x, 3) for x in v] for c, v in best.items()}, flush=True)
+        print(dtype, {c: [round(x, 3) for x in v] for c, v in best.items()}, flush=True)
         del st, m
         torch.cuda.empty_cache()
 
