@@ -712,8 +712,16 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             double best = c256;
             if (c192 < best) { best = c192; ring = 7; }
             if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(17, d) && csq < best) { best = csq; ring = 17; }
+            // 192 x 256 ring (18: eight waves, 2 x 56 KB, one per CU): M = 16000, N = 768 is 252 tiles on 256 CUs; +3..11 % over
+            // ring 7 on the N = 768 / 2304 products
+            const int64_t r18 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 256) * d.batch + slots - 1) / slots;
+            const double c18 = (double)r18 * 384.0 / 1.05;
+            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(18, d) && c18 < best) { best = c18; ring = 18; }
         } else if (bm192) {
             ring = 8;             // bf16: wherever 192-row tiles fill the grid better (N = 768 / 2304: +3..10 %)
+            // one 192 x 256 tile per CU (19) instead of two 192 x 128 (8) where it needs no more rounds: +1..3 % (N = 768)
+            const int64_t r8 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 128) * d.batch + 511) / 512, r19 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 256) * d.batch + 255) / 256;
+            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(19, d) && r19 <= r8) ring = 19;
         } else if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(2, d)) {
             // bf16, 256 x 256 ring (2): ties the register-staged 256 x 128 kernel on time (within 3 %) where its tiles
             // fill the grid equally well, and halves the A-panel fetches from the fabric (profiles/r2_kgroup_pmc.txt)

@@ -314,6 +314,8 @@ void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
         case 15: launch_ring<256, 256, 32, 0, 4, 2, 2, true, 1>(g, st); break;  // bf16, four waves of 128 x 128, 4 x 32 KB, certified one ahead
         case 16: launch_ring<256, 256, 32, 1, 2, 2, 2, false, 1>(g, st); break; // split, four waves of 128 x 128, 2 x 64 KB
         case 17: launch_ring<256, 256, 32, 1, 2, 2, 4, false>(g, st); break;    // split, 256 x 256, eight waves, 2 x 64 KB: the A panel is shared by 2 column tiles instead of 4
+        case 18: launch_ring<192, 256, 32, 1, 2, 2, 4, false>(g, st); break;    // split, 192 x 256, eight waves, 2 x 56 KB, one per CU (M = 16000, N = 768: 252 tiles on 256 CUs)
+        case 19: launch_ring<192, 256, 64, 0, 2, 2, 4, false>(g, st); break;    // bf16, 192 x 256, eight waves, 2 x 56 KB, one per CU
         case 9: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2, true>(g, st); break;    // PROBE (wrong results): cfg 7 with 16x16x32 MFMAs
         case 10: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2, true>(g, st); break;   // PROBE (wrong results): cfg 8 with 16x16x32 MFMAs
         default: break;
@@ -337,16 +339,16 @@ extern "C" double paa_debug_ring_clock_ghz(int n_blocks) {
 namespace paa {
 #endif
 
-int ring_tile_rows(int cfg) { return (cfg >= 7 && cfg <= 13) ? 192 : 256; }
+int ring_tile_rows(int cfg) { return ((cfg >= 7 && cfg <= 13) || cfg == 18 || cfg == 19) ? 192 : 256; }
 int ring_tile_cols(int cfg) { return (cfg == 4 || (cfg >= 6 && cfg <= 13)) ? 128 : 256; }
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
-    if (cfg < 2 || cfg > 17 || cfg == 13) return false;
+    if (cfg < 2 || cfg > 19 || cfg == 13) return false;
     // 9 / 10 are timing probes with WRONG results (MF16): only reachable when the measurement script asks for them
     static const bool probes = getenv("PAA_MF16_PROBE") != nullptr;
     if ((cfg == 9 || cfg == 10) && !probes) return false;
-    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16 || cfg == 17;
+    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16 || cfg == 17 || cfg == 18;
     if (split != (d.precision != 0)) return false;
-    const int bk = (cfg == 2 || cfg == 8 || cfg == 10 || cfg == 14) ? 64 : cfg == 11 ? 16 : 32;
+    const int bk = (cfg == 2 || cfg == 8 || cfg == 10 || cfg == 14 || cfg == 19) ? 64 : cfg == 11 ? 16 : 32;
     return d.K % bk == 0 && d.K >= 4 * bk;
 }
 
