@@ -36,7 +36,9 @@ VARIANTS = {v: (f"k_gemm_bf<{'256' if v & 32 else '128'},{'64' if v & 8 else '12
                 f"k_gemm<{'64' if v & 8 else '128'},{'split' if v & 4 else 'bf16'},A{'k' if v & 2 else 'm'},B{'k' if v & 1 else 'n'}>")
             for v in range(64)}
 VARIANTS.update({51: "k_gemm_bf<256,128,bf16>", 55: "k_gemm_bf<256,128,split>", 59: "k_gemm_bf<192,128,bf16>",
-                 40: "k_gemm_win<bf16>", 44: "k_gemm_win<split>", 60: "k_gemm_ring<bf16>", 61: "k_gemm_ring<192,128,split>"})
+                 40: "k_gemm_win<bf16>", 44: "k_gemm_win<split>", 60: "k_gemm_ring<192,128,bf16>", 61: "k_gemm_ring<192,128,split>", 56: "k_gemm_ring<256,256,bf16>",
+                 57: "k_gemm_ring<256,256,split>", 52: "k_gemm_ring<192,256,bf16>", 53: "k_gemm_ring<192,256,split>",
+                 48: "k_gemm_ring<256,128,bf16>", 49: "k_gemm_ring<256,128,split>"})
 DTYPE_NAME = {"fp32": "bf16x3 (split-bf16 hi+lo, three MFMA passes, f32 accumulate: fp32-parity)", "bf16": "bf16"}
 MFMA_PEAK = 2500.0       # dense bf16 TFLOP/s (MI355X_MICROARCH.md); a split-mode product issues three such MFMAs
 

@@ -784,7 +784,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         }
     }
     if (ring) {
-        if (prof) g_prof.variant[g_prof.n] = d.precision ? 61 : 60;
+        // ring variants by tile: 192 x 128 -> 60 / 61 (bf16 / split), 256 x 256 -> 56 / 57, 192 x 256 -> 52 / 53, 256 x 128 -> 48 / 49
+        if (prof) g_prof.variant[g_prof.n] = (ring_bm == 192 ? (ring_bn == 128 ? 60 : 52) : (ring_bn == 256 ? 56 : 48)) + (d.precision ? 1 : 0);
         if (ring == 13) launch_bf<192, 128, 1, 2, true, false, true>(g, st);
         else launch_ring_cfg(ring, g, st);
     } else if (d.operand_bf16) {
@@ -828,7 +829,8 @@ extern "C" paa_status paa_prof_enable(int max_launches) {
 
 // out[64][4] = per kernel variant {launches, total ms, total algorithmic FLOP, total algorithmic HBM bytes}
 // (variant = tall*32 + bf16_operands*16 + (narrow | tall-with-192-rows)*8 + split*4 + a_kcontig*2 + b_kcontig; 40 / 44: the slab
-// kernel of the grouped positional convolution, bf16 / split; 60 / 61: the LDS-DMA ring kernels, bf16 / split).
+// kernel of the grouped positional convolution, bf16 / split; the LDS-DMA ring kernels, bf16 / split, by tile: 60 / 61 = 192 x 128,
+// 56 / 57 = 256 x 256, 52 / 53 = 192 x 256, 48 / 49 = 256 x 128 — ids the bit formula never produces).
 // Synchronises on the last recorded event.  Resets the counters.
 extern "C" paa_status paa_prof_read(double* out256) {
     using namespace paa;

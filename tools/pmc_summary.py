@@ -34,7 +34,7 @@ def variant_of(kernel: str):
     """PMC kernel name -> the label bench.py's roofline uses for the same launches (None: not a GEMM)."""
     m = re.search(r"k_gemm_ring<(\d+), (\d+), (\d+), (\d+)", kernel)
     if m:
-        return "k_gemm_ring<192,128,split>" if m.group(4) == "1" else "k_gemm_ring<bf16>"
+        return f"k_gemm_ring<{m.group(1)},{m.group(2)},{'split' if m.group(4) == '1' else 'bf16'}>"
     m = re.search(r"k_gemm_bf<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>", kernel)
     if m:
         bm, bn, prec = m.group(1), m.group(2), "split" if m.group(3) == "1" else "bf16"
@@ -74,6 +74,14 @@ def main():
                 k["algorithmic_bytes_per_launch"] = int(alg[v] * 1e6)
                 k["pmc_over_algorithmic"] = round(k["hbm_bytes_per_launch"] / (alg[v] * 1e6), 3)
         kernels.append(k)
+    # launches that do not recur every step (model construction: workspace fills, weight preparation) are listed apart and kept
+    # out of the per-step totals
+    setup = [k for k in kernels if k["launches_per_step"] < 1.0]
+    kernels = [k for k in kernels if k["launches_per_step"] >= 1.0]
+    for k in setup:
+        k["note"] = "setup (not per step): totals over the run, GB"
+        k["fetch_GB_total"] = round(k.pop("fetch_GB_per_step") * steps, 3)
+        k["write_GB_total"] = round(k.pop("write_GB_per_step") * steps, 3)
     kernels.sort(key=lambda k: -(k["fetch_GB_per_step"] + k["write_GB_per_step"]))
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --dtype <dtype> --steps 2 "
                    "--warmup 1 --no_cpu_baseline --no_fft_bench --no_prof`; KB units x1024; FETCH_SIZE doubled per the gfx950 correction "
@@ -83,7 +91,7 @@ def main():
            "dtype": dtype,
            "total_fetch_GB_per_step": round(sum(k["fetch_GB_per_step"] for k in kernels), 2),
            "total_write_GB_per_step": round(sum(k["write_GB_per_step"] for k in kernels), 2),
-           "kernels": kernels}
+           "kernels": kernels, "setup_kernels": setup}
     json.dump(out, sys.stdout, indent=1)
 
 
