@@ -48,14 +48,14 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
     constexpr int LO = DG_T * DG_RS;           // hi -> lo tile distance in LDS
 
     // W1_b fragments of this wave's k-steps (k-step ks = w + 4 i): column j = lr, elements 16 ks + 8 lh ..
-    // (PREC: the lo fragments are re-read per tile — 8 L1-resident 16-byte loads — rather than held: holding both planes
+    // (PREC: both planes' fragments are re-read per tile — 16 L1-resident 16-byte loads — rather than held: holding them
     // next to the 64 accumulators and the two register-staged tiles does not fit 256 VGPRs)
     bf16x8 wf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ks = w + 4 * i;
         bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ks < nks && lr < 16) z = *reinterpret_cast<const bf16x8*>(a.w1b.hi + ((size_t)b * 16 + lr) * C + 16 * ks + 8 * lh);
+        if (!PREC && ks < nks && lr < 16) z = *reinterpret_cast<const bf16x8*>(a.w1b.hi + ((size_t)b * 16 + lr) * C + 16 * ks + 8 * lh);
         wf[i] = z;
     }
     f32x16 sacc[4];
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[i][e] = 0.f;
 
-    // (PREC: only the hi plane is register-staged across the compute phase; the lo plane is loaded inside stage(), its
-    // latency covered by the other workgroup of the CU — both planes in registers spill)
-    uint4 st[8];
+    // (PREC: the hi plane of the next tile is requested before the G1 phase, the lo plane after it — both planes next to
+    // the G1 phase's fragments do not fit 256 VGPRs; the lo loads have the S phase to land)
+    uint4 st[8], stl[PREC ? 8 : 1];
     auto fetch = [&](int t0) {            // tile rows -> registers (rows >= T read as zero: pad rows may hold anything)
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
@@ -77,31 +77,24 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
             st[v] = z;
         }
     };
+    auto fetch_lo = [&](int t0) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int idx = tid + 256 * v;
+            const int row = idx / cpr, col = idx - row * cpr;
+            uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < nchunks && t0 + row < a.T) z = *reinterpret_cast<const uint4*>(dyl + (size_t)(t0 + row) * C + 8 * col);
+            stl[v] = z;
+        }
+    };
     auto stage = [&](int t0) {            // registers -> LDS tile, input window -> xs
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const int idx = tid + 256 * v;
             const int row = idx / cpr, col = idx - row * cpr;
-            if (idx < nchunks) *reinterpret_cast<uint4*>(tile + row * DG_RS + 8 * col) = st[v];
-        }
-        if (PREC) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint4 stl[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int idx = tid + 256 * (4 * h + v);
-                    const int row = idx / cpr, col = idx - row * cpr;
-                    uint4 zl = make_uint4(0u, 0u, 0u, 0u);
-                    if (idx < nchunks && t0 + row < a.T) zl = *reinterpret_cast<const uint4*>(dyl + (size_t)(t0 + row) * C + 8 * col);
-                    stl[v] = zl;
-                }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int idx = tid + 256 * (4 * h + v);
-                    const int row = idx / cpr, col = idx - row * cpr;
-                    if (idx < nchunks) *reinterpret_cast<uint4*>(tile + LO + row * DG_RS + 8 * col) = stl[v];
-                }
+            if (idx < nchunks) {
+                *reinterpret_cast<uint4*>(tile + row * DG_RS + 8 * col) = st[v];
+                if (PREC) *reinterpret_cast<uint4*>(tile + LO + row * DG_RS + 8 * col) = stl[v];
             }
         }
         if (tid < (DG_T - 1) * 5 + 10) {
@@ -111,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
     };
 
     int t0 = blockIdx.x * DG_T;
-    if (blockIdx.x < ntiles) { fetch(t0); stage(t0); }
+    if (blockIdx.x < ntiles) { fetch(t0); if (PREC) fetch_lo(t0); stage(t0); }
     __syncthreads();
     for (int tl = blockIdx.x; tl < ntiles; tl += nblk) {
         t0 = tl * DG_T;
@@ -123,7 +116,8 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) g[e] = 0.f;
         const unsigned short* wlo = PREC ? a.w1b.lo + ((size_t)b * 16 + (lr & 15)) * C + 8 * lh : nullptr;
-        if (PREC) asm volatile("" : "+v"(wlo));          // opaque per tile: keeps these loads inside the loop
+        const unsigned short* whi = PREC ? a.w1b.hi + ((size_t)b * 16 + (lr & 15)) * C + 8 * lh : nullptr;
+        if (PREC) { asm volatile("" : "+v"(wlo)); asm volatile("" : "+v"(whi)); }    // opaque per tile: keeps these loads inside the loop
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ks = w + 4 * i;
@@ -131,13 +125,20 @@ __global__ __launch_bounds__(256, 2) void k_conv0_dgrad(Conv0Args a) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(tile + lr * DG_RS + 16 * ks + 8 * lh);
                 if (PREC) {
                     const bf16x8 afl = *reinterpret_cast<const bf16x8*>(tile + LO + lr * DG_RS + 16 * ks + 8 * lh);
-                    bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlo + 16 * ks);
-                    if (lr >= 16) wl = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl, wf[i], g, 0, 0, 0);
+                    bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlo + 16 * ks), wh = *reinterpret_cast<const bf16x8*>(whi + 16 * ks);
+                    if (lr >= 16) { wl = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; wh = wl; }
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl, wh, g, 0, 0, 0);
                     g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wl, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wh, g, 0, 0, 0);
+                } else {
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[i], g, 0, 0, 0);
                 }
-                g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[i], g, 0, 0, 0);
             }
+        }
+        if (PREC) {
+            __builtin_amdgcn_sched_barrier(0);        // keep the lo requests (32 registers) below the G1 phase
+            if (more) fetch_lo(tn);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- X fragments (column j = lr; k order of the transposing read: frames 16 s + 4 lh + (0..3), then + 8)
         bf16x8 xh[2], xl[2];
