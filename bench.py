@@ -46,7 +46,7 @@ MFMA_PEAK = 2500.0       # dense bf16 TFLOP/s (MI355X_MICROARCH.md); a split-mod
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=64)     # >= 2 s of timed region in the headline mode (38 ms per step)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)

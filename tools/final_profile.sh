@@ -11,7 +11,7 @@ timeout -k 10 600 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 |
 tail -1 $O/pytest_gpu.log
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log
-timeout -k 10 400 python bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+timeout -k 10 400 python bench.py --steps 64 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 cut -c1-200 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 for DT in fp32 bf16; do
@@ -27,7 +27,7 @@ for DT in fp32 bf16; do
 done
 cd $R
 # headline line again with the PMC traffic of this commit filled in
-timeout -k 10 300 python bench.py --dtype fp32 --steps 50 --warmup 5 --no_cpu_baseline --no_fft_bench --pmc_json $O/hbm_traffic_pmc_fp32.json > $O/bench_fp32_with_traffic.json 2>/dev/null; cut -c1-120 $O/bench_fp32_with_traffic.json
+timeout -k 10 300 python bench.py --dtype fp32 --steps 64 --warmup 5 --no_cpu_baseline --no_fft_bench --pmc_json $O/hbm_traffic_pmc_fp32.json > $O/bench_fp32_with_traffic.json 2>/dev/null; cut -c1-120 $O/bench_fp32_with_traffic.json
 # two ranks sharing the one GPU over gloo through bench.py's own launcher (RCCL needs one device per rank)
 PAA_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 4 --seconds 2 --label_tokens 30 --no_cpu_baseline --no_fft_bench > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; cut -c1-200 $O/bench_2rank_gloo.json
 bash tools/fft_profile.sh > $O/fft_profile.log 2>&1; tail -4 $O/fft_profile.log
