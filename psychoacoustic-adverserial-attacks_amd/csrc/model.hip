@@ -47,6 +47,7 @@ struct ConvL {
     std::vector<int> wdQ;
     float *pre = nullptr, *act_f = nullptr, *cv = nullptr, *row_stats = nullptr;
     bool pre16 = false;                // pre holds bf16 (see paa_model::pre16)
+    bool gate = false;                 // pre holds gelu'(v) instead of v (both modes; see paa_model::pre16)
     Bf actb{nullptr, nullptr};
 };
 
@@ -102,9 +103,13 @@ struct paa_model {
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
     bool fused;                      // flash-style attention kernels (head_dim 64); else materialised scores
-    bool pre16;                      // bf16 mode: what a GELU keeps for its backward pass (L{l}.fpre, and conv{i}.pre, i < last,
-                                     // of the group-norm extractor) is stored as bf16 AND as the derivative gelu'(v) itself
-                                     // (paa_gemm_desc.aux_bf16 / aux_gate): it only ever multiplies a gradient
+    bool gate;                       // see pre16; false only in fp32-parity mode under PAA_NO_GATE32=1 (A/B measurements)
+    bool pre16;                      // What a GELU keeps for its backward pass (L{l}.fpre, and conv{i}.pre, i < last, of the
+                                     // group-norm extractor) is the derivative gelu'(v) itself in BOTH modes (paa_gemm_desc.aux_gate;
+                                     // ConvL::gate): it only ever multiplies a gradient, and evaluating it next to the GELU that
+                                     // shares its exp takes ~20 instructions per element out of every backward epilogue — same
+                                     // function of the same input, evaluated in the forward pass.  bf16 mode (pre16) also stores
+                                     // it as bf16 (paa_gemm_desc.aux_bf16)
     std::vector<ConvL> conv;
     std::vector<EncL> enc;
     std::map<std::string, std::pair<const float*, int64_t>> tensors;
@@ -166,6 +171,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
     m->fused = a.hidden / a.heads == 64;      // flash-style kernels; split-bf16 (hi + lo planes) in fp32-parity mode
     m->pre16 = m->prec == 0;
+    { const char* e = getenv("PAA_NO_GATE32"); m->gate = m->pre16 || !(e && e[0] == '1'); }
     for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
 
     // ---- shapes: conv output lengths and the padded row counts (P_{i-1} = s_i * P_i) ----
@@ -254,7 +260,8 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         for (int i = 0; i < nc; ++i) {
             ConvL& c = m->conv[i];
             const int64_t n = ((int64_t)B * c.P + GUARD) * c.cout;
-            c.pre16 = m->pre16 && !a.feat_norm_layer && i < nc - 1;
+            c.gate = m->gate && !a.feat_norm_layer && i < nc - 1;
+            c.pre16 = m->pre16 && c.gate;
             c.pre = take(c.pre16 ? (n + 1) / 2 : n);
             if (i < nc - 1) c.actb = take_bf(n); else c.act_f = take(n);
             if (a.feat_norm_layer) { if (i) c.cv = take(n); c.row_stats = take((int64_t)B * c.P * 2); }
@@ -342,7 +349,8 @@ static paa_status linear(const paa_model* m, CBf x, CBf w, const float* bias, fl
                          const float* aux = nullptr, bool x16 = false) {
     paa_gemm_desc d = gdb(m, x, w, y, yb, M, N, K, K, K, N);
     d.bias = bias; d.residual = residual; d.ld_res = N; d.act = act; d.C_pre = pre; d.aux = aux; d.ld_aux = N;
-    d.aux_bf16 = x16 ? 1 : 0; d.aux_gate = d.aux_bf16;     // bf16-stored pre-activations hold gelu'(v)
+    d.aux_bf16 = x16 ? 1 : 0;
+    d.aux_gate = (m->gate && (act == PAA_ACT_GELU || act == PAA_ACT_GELU_GRAD)) ? 1 : 0;     // kept pre-activations hold gelu'(v) (paa_model::pre16)
     return gemm(d, st);
 }
 
@@ -356,7 +364,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         Conv0Args ca{};
         ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
         ca.k = c.k; ca.stride = c.s; ca.w = c.w0; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
-        ca.pre = c.pre; ca.pre16 = c.pre16; ca.actb = c.actb; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
+        ca.pre = c.pre; ca.pre16 = c.pre16; ca.gate = c.gate; ca.actb = c.actb; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
         if (a.feat_norm_layer) PAA_TRY(conv0_ln_forward(ca, st)); else PAA_TRY(conv0_gn_forward(ca, m->c0_part, st));
     }
     for (int i = 1; i < nc; ++i) {
@@ -373,7 +381,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             PAA_TRY(layernorm_fwd(c.cv, c.g, c.beta, c.pre, c.row_stats, B * c.P, c.cout, 1e-5f, NOBF, last ? NOBF : c.actb,
                                   last ? c.act_f : nullptr, st));
         } else {
-            d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.aux_gate = d.aux_bf16; d.act = PAA_ACT_GELU;
+            d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.aux_gate = c.gate ? 1 : 0; d.act = PAA_ACT_GELU;
             if (last) d.C = c.act_f; else { d.Cb = c.actb.hi; d.Cb_lo = c.actb.lo; }
             PAA_TRY(gemm(d, st));
         }
@@ -581,7 +589,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             d.k_group = kgroup_on() ? c.cout : 0;
             if (out_f32) d.C = m->gF[jo] + (int64_t)rho * c.cin;
             else { Bf o = boff(m->gH[jo], (int64_t)rho * c.cin); d.Cb = o.hi; d.Cb_lo = o.lo; }
-            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_gate = d.aux_bf16;
+            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_gate = pr.gate ? 1 : 0;
             d.aux = pr.pre16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(pr.pre) + (int64_t)rho * c.cin)
                              : pr.pre + (int64_t)rho * c.cin;
             PAA_TRY(gemm(d, st));
@@ -664,7 +672,7 @@ extern "C" void paa_abi_sizes(int32_t* out4) {
 }
 
 // Test/diagnostic access to the internal activations (synchronous copy to host as f32; never on the step path).
-// In bf16 mode conv{i}.pre (i < last, group-norm extractor) and L{l}.fpre return gelu'(pre) (see paa_model::pre16).
+// conv{i}.pre (i < last, group-norm extractor) and L{l}.fpre return gelu'(pre) in both modes (see paa_model::pre16).
 // f32 buffers: conv{i}.pre, conv{last}.act, conv{i}.cv, h0, pos_pre, hsum, logits, dlogits, nll, G, gbuf0, dh0, dfn, dxa,
 //              gn_stats, L{l}.qkv|P|ln1_in|fpre|ln2_in.   bf16 planes (hi + lo summed): conv{i}.act (i < last), fn, xfinal.
 extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* host, int64_t max_floats, int B) {

@@ -270,6 +270,10 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                             f32x2 dg;
                             g = gelu_both_fast2(y, dg);
                             *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(a.pre) + o) = bf16_bits(dg.x) | ((unsigned)bf16_bits(dg.y) << 16);
+                        } else if (a.gate) {                 // fp32-parity mode: keep gelu'(y) as f32; the branch-free erf (|error| <= 1.5e-7)
+                            f32x2 dg;                        // of every other GELU of this mode (gemm_dev.h, epilogue_vec): with libm's erff for
+                            g = gelu_both_fast2(y, dg);      // both the GELU and its derivative this HBM-sized kernel turns VALU-bound (+1 % of the step)
+                            *reinterpret_cast<float2*>(a.pre + o) = make_float2(dg.x, dg.y);
                         } else {
                             g = f32x2{gelu_f(y.x), gelu_f(y.y)};
                             *reinterpret_cast<float2*>(a.pre + o) = make_float2(y.x, y.y);
@@ -310,6 +314,11 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                         float dg;
                         const float gy = gelu_both_fast(y, dg);
                         reinterpret_cast<unsigned short*>(a.pre)[o] = bf16_bits(dg);
+                        store_bf16(a.actb, o, gy);
+                    } else if (a.gate) {
+                        float dg;
+                        const float gy = gelu_both_fast(y, dg);
+                        a.pre[o] = dg;
                         store_bf16(a.actb, o, gy);
                     } else {
                         a.pre[o] = y;
