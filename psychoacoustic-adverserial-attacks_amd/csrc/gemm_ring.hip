@@ -25,6 +25,12 @@ namespace paa {
 // whole tile loop, written to a buffer of their own that nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6).
 __device__ unsigned long long g_clock_stamp[2 * 1024];
 #endif
+// Diagnostic builds only (tools/gemm_ablate.sh, never the shipped library): -DPAA_ABL=<bits> removes parts of the kernel to price
+// them — 1: no epilogue (the accumulators are only summed), 2: no operand DMA, 4: no workgroup barrier, 8: no fragment reads
+// inside the K loop.  Results are WRONG under any bit.
+#ifndef PAA_ABL
+#define PAA_ABL 0
+#endif
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 template <int N>
@@ -120,9 +126,11 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     };
     auto issue = [&](int slot) {
         unsigned char* st = smem + slot * STAGE;
+        if (!(PAA_ABL & 2)) {
 #pragma unroll
-        for (int i = 0; i < GPW; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lslab * BK), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
+            for (int i = 0; i < GPW; ++i)
+                __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + (int64_t)lslab * BK), (las_ptr)(st + (i * NW + wave) * 1024), 16, 0, 0);
+        }
         if (kg_spt) {
             if (++ltap == kg_taps) { ltap = 0; ++lc; }
             lslab = ltap * kg_spt + lc;
@@ -169,11 +177,13 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
     if constexpr (AHEAD) {                     // stages 0 and 1 landed everywhere; stage 0's first fragments in registers
         if (pend >= 3) wait_vmcnt<(D >= 3 ? 1 : 0) * GPW>(); else wait_vmcnt<0>();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!(PAA_ABL & 4)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         first_frags(0);
     }
     bool first_it = true;
+    bool first_abl = true;
+    (void)first_abl;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const Tile cur = decode(t);
         f32x16 acc[NJ / 2][MI][2];             // [64-column group][row block][column block]: one epilogue_vec per group
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
                 if (!first_it) {
                     if (pend >= 3) wait_vmcnt<(D >= 3 ? 1 : 0) * GPW>(); else wait_vmcnt<0>();
                     __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
+                    if (!(PAA_ABL & 4)) __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 first_it = false;
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
                 else if (pend == 2) wait_vmcnt<(D >= 2 ? 1 : 0) * GPW>();
                 else wait_vmcnt<0>();
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();      // everyone's have; everyone is done reading the slot refilled next
+                if (!(PAA_ABL & 4)) __builtin_amdgcn_s_barrier();      // everyone's have; everyone is done reading the slot refilled next
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (lt < total) { issue(islot); islot = islot + 1 == NST ? 0 : islot + 1; } else --pend;
@@ -213,7 +223,10 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) { bh[j] = bhn[j]; bl[j] = bln[j]; }
                 ah = ahn; al = aln;
+            } else if ((PAA_ABL & 8) && !first_abl) {
+                // fragments stay what they were
             } else {
+                first_abl = false;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     bh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[0]);
@@ -230,7 +243,8 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
-                    if (nks < KS) {
+                    if ((PAA_ABL & 8)) {
+                    } else if (nks < KS) {
                         ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 32 * RB + offk[nks < KS ? nks : 0]);
                         if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + LO + ni * 32 * RB + offk[nks < KS ? nks : 0]);
                         if (ni == 0) {
@@ -268,6 +282,19 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
                         }
                     }
                 }
+        }
+        if (PAA_ABL & 1) {
+            float sum = 0.f;
+#pragma unroll
+            for (int h = 0; h < NJ / 2; ++h)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) sum += acc[h][i][j][e];
+            if (sum == 12345.678f && d.Cb) reinterpret_cast<unsigned short*>(d.Cb)[lane] = 1;
+            continue;
         }
         epilogue_vec<MI, true>(d, acc[0], cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
         if constexpr (NJ == 4)      // (written out: a loop over the groups is not unrolled and sends the accumulators through scratch)
