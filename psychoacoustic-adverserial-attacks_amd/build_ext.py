@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpaa_hip.so")
-SOURCES = ["proj_kernels.hip", "spec_kernels.hip", "gemm.hip", "gemm_ring.hip", "model_kernels.hip", "conv0_dgrad.hip", "attention.hip", "model.hip"]
+SOURCES = ["proj_kernels.hip", "spec_kernels.hip", "gemm.hip", "gemm_ring.hip", "gemm_ring2.hip", "model_kernels.hip", "conv0_dgrad.hip", "attention.hip", "model.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value"] + os.environ.get("PAA_EXTRA_HIPCC_FLAGS", "").split()
 
 

@@ -612,6 +612,7 @@ static void launch_bf(const GemmArgs& g, hipStream_t st) {
 
 // gemm_ring.hip: LDS-DMA ring kernels (configuration ids: see launch_ring_cfg)
 void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st);
+void launch_ring2_cfg(int cfg, const GemmArgs& g, hipStream_t st);      // gemm_ring2.hip: configurations 20..23
 int ring_tile_rows(int cfg);
 int ring_tile_cols(int cfg);
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d);
@@ -729,6 +730,13 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             const int64_t r2 = (t128 + slots2 - 1) / slots2, rsq = (t256 + 255) / 256;
             if (rsq <= r2) ring = 2;      // a round is one 256 x 256 tile or two co-resident 256 x 128 tiles per CU: equal work
         }
+        // separate operand rings (gemm_ring2.hip: three A slots, two B slots) for the 256-column tiles: +0..5 % per product over the
+        // two-stage rings; PAA_NO_R2=1 (A/B measurements, read per call) keeps the two-stage forms
+        if (g_ring_mode < 2 && (ring == 17 || ring == 2 || ring == 18 || ring == 19)) {
+            const char* nr2 = getenv("PAA_NO_R2");
+            const int r2 = ring == 17 ? 20 : ring == 2 ? 21 : ring == 18 ? 22 : 23;
+            if (!(nr2 && nr2[0] == '1') && ring_cfg_ok(r2, d)) ring = r2;
+        }
         if (ring == 13) { if (!d.precision) ring = 0; }          // 13: register-staged 192 x 128 split tile, swizzled LDS, two workgroups per CU
         else if (ring && !ring_cfg_ok(ring, d)) ring = 0;
     }
@@ -787,6 +795,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         // ring variants by tile: 192 x 128 -> 60 / 61 (bf16 / split), 256 x 256 -> 56 / 57, 192 x 256 -> 52 / 53, 256 x 128 -> 48 / 49
         if (prof) g_prof.variant[g_prof.n] = (ring_bm == 192 ? (ring_bn == 128 ? 60 : 52) : (ring_bn == 256 ? 56 : 48)) + (d.precision ? 1 : 0);
         if (ring == 13) launch_bf<192, 128, 1, 2, true, false, true>(g, st);
+        else if (ring >= 20) launch_ring2_cfg(ring, g, st);
         else launch_ring_cfg(ring, g, st);
     } else if (d.operand_bf16) {
         const bool seg = d.a_kseg > 0 || (d.K & 63);          // segmented / windowed A or a K tail: general loader

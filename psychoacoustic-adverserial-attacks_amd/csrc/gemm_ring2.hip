@@ -1,0 +1,265 @@
+// LDS-DMA ring GEMM with SEPARATE rings for the two operands (gfx950; contract in gemm.h, epilogues in gemm_dev.h).
+//
+// gemm_ring.hip keeps A and B slabs of one K step in one stage, so a 256 x 256 tile (64 KB per stage) has ONE stage of
+// lookahead in 160 KB of LDS: 0.5 us (bf16) / 0.7 us (split) of MFMA work to cover a fetch from HBM.  The ablation builds of
+// that kernel (tools/gemm_ablate.sh, profiles/r2_gemm_ablation.txt) price the wait for operands from real memory at 20 % of
+// the conv products.  Here the A operand — the activations, streamed from HBM — gets THREE slots (two stages of lookahead)
+// and the B operand — the weights, re-read from L2 by every workgroup — two (one stage): 3 x 32 + 2 x 32 KB = all of the LDS
+// for a 256 x 256 tile.  Per K slab s, in this order:
+//     issue B(s + 1), A(s + 2)   |   MFMAs on A(s), B(s)   |   s_waitcnt vmcnt(A(s + 2) in flight)   |   barrier   |   epilogue if last
+// vmcnt retires in issue order on gfx9, so with B issued BEFORE A inside a step the counted wait lets exactly the
+// far-ahead A slab stay in flight while B(s + 1) and A(s + 1) are certified for the next step; the one barrier per step also
+// frees the slots the next step refills.  The epilogue's stores sit behind the barrier: they drain under the next step's
+// MFMAs instead of in front of its first wait.  Same fragment layout, swizzle, K order and epilogue as gemm_ring.hip, so
+// results are bit-identical to it.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "gemm_dev.h"
+
+namespace paa {
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gas_ptr2;
+typedef __attribute__((address_space(3))) void* las_ptr2;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt2() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int BK, int PREC, int WR, int WC>
+__global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
+    constexpr int NW = WR * WC;
+    constexpr int NPL = PREC ? 2 : 1;
+    constexpr int RB = BK * 2;                 // bytes per LDS row (one plane)
+    constexpr int CPR = RB / 16;               // 16-byte chunks per row
+    constexpr int RPI = 1024 / RB;             // rows per DMA wave-instruction
+    constexpr int RBR = 256 / RB;              // rows per 256-byte bank row
+    constexpr int NSTA = 3, NSTB = 2;
+    constexpr int ASZ = NPL * BM * RB, BSZ = NPL * BN * RB;        // one slot of each ring: hi rows [| lo rows]
+    constexpr int GA = NPL * BM / RPI / NW, GB = NPL * BN / RPI / NW;   // DMA wave-instructions per wave per slab
+    constexpr int MI = BM / WR / 32, NJ = BN / WC / 32, KS = BK / 16;
+    static_assert(NJ == 2, "vector epilogue: 64 columns per wave");
+    static_assert((NPL * BM) % (RPI * NW) == 0 && (NPL * BN) % (RPI * NW) == 0 && BM % RPI == 0 && BN % RPI == 0, "a DMA wave-instruction must not straddle planes");
+    static_assert(NSTA * ASZ + NSTB * BSZ <= 160 * 1024 && GA + GB < 32, "rings do not fit");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTA * ASZ + NSTB * BSZ];
+    unsigned char* const smA = smem;
+    unsigned char* const smB = smem + NSTA * ASZ;
+
+    const paa_gemm_desc& d = g.d;
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int total = nwg * d.batch;
+    const int nk = d.K / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int lr = lane & 31, lh = lane >> 5;
+    if ((int)blockIdx.x >= total) return;
+
+    struct Tile { int m0, n0, z1, z2; };
+    auto decode = [&](int t) {
+        Tile c;
+        const int z = t / nwg, orig = t - z * nwg;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
+        c.m0 = tm * BM; c.n0 = tn * BN;
+        c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
+        return c;
+    };
+    // k_group order of the K slabs (gemm.h): kg_spt slabs per tap, kg_taps taps; 0 = plain K order
+    const int kg_spt = (d.k_group > 0 && d.k_group % BK == 0 && d.K % d.k_group == 0 && d.K > d.k_group) ? d.k_group / BK : 0;
+    const int kg_taps = kg_spt ? d.K / d.k_group : 1;
+
+    // ---- load cursors: the next (tile, K slab) each operand requests ----------------------------------------------------
+    struct Cursor { int t, k, tap, c, slab, slot; };
+    auto advance = [&](Cursor& u, int nslots) {        // returns true when the cursor moved on to another tile
+        u.slot = u.slot + 1 == nslots ? 0 : u.slot + 1;
+        if (kg_spt) {
+            if (++u.tap == kg_taps) { u.tap = 0; ++u.c; }
+            u.slab = u.tap * kg_spt + u.c;
+        } else {
+            ++u.slab;
+        }
+        if (++u.k == nk) {
+            u.k = 0; u.tap = 0; u.c = 0; u.slab = 0;
+            u.t += gridDim.x;
+            return true;
+        }
+        return false;
+    };
+    Cursor ca{(int)blockIdx.x, 0, 0, 0, 0, 0}, cb = ca;
+    const unsigned short* srcA[GA];
+    const unsigned short* srcB[GB];
+    auto set_srcA = [&](int t) {
+        const Tile c = decode(t);
+        const int64_t aoff = c.z1 * d.a_s1 + c.z2 * d.a_s2;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const int r = (i * NW + wave) * RPI + lane / CPR;             // row of the slot: hi rows, then lo rows
+            const int pl = r / BM, rr = r - pl * BM;
+            const int ch = (lane % CPR) ^ ((rr / RBR) & (CPR - 1));       // global chunk that lands in slot lane % CPR
+            const unsigned short* A = reinterpret_cast<const unsigned short*>(pl ? d.A_lo : (const void*)d.A) + aoff;
+            srcA[i] = A + (int64_t)min(c.m0 + rr, d.M - 1) * d.lda + ch * 8;
+        }
+    };
+    auto set_srcB = [&](int t) {
+        const Tile c = decode(t);
+        const int64_t boff = c.z1 * d.b_s1 + c.z2 * d.b_s2;
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            const int r = (i * NW + wave) * RPI + lane / CPR;
+            const int pl = r / BN, p = r - pl * BN;
+            const int ch = (lane % CPR) ^ ((p / RBR) & (CPR - 1));
+            const unsigned short* B = reinterpret_cast<const unsigned short*>(pl ? d.B_lo : (const void*)d.B) + boff;
+            const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);      // row permutation of the vector epilogue
+            srcB[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
+        }
+    };
+    auto issueA = [&]() {                      // -> true if a slab was requested
+        if (ca.t >= total) return false;
+        unsigned char* st = smA + ca.slot * ASZ;
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcA[i] + (int64_t)ca.slab * BK), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
+        if (advance(ca, NSTA) && ca.t < total) set_srcA(ca.t);
+        return true;
+    };
+    auto issueB = [&]() {
+        if (cb.t >= total) return;
+        unsigned char* st = smB + cb.slot * BSZ;
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcB[i] + (int64_t)cb.slab * BK), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
+        if (advance(cb, NSTB) && cb.t < total) set_srcB(cb.t);
+    };
+    set_srcA(ca.t);
+    set_srcB(cb.t);
+    issueB();                                  // B(0)
+    issueA();                                  // A(0)
+    bool ahead = issueA();                     // A(1): the one slab that may stay in flight across the certifying wait
+    if (ahead) wait_vmcnt2<GA>(); else wait_vmcnt2<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();              // slab 0 of both operands has landed everywhere
+    __builtin_amdgcn_sched_barrier(0);
+
+    // fragment addressing: row base + swizzled 16-byte chunk of the k slice
+    const int sw = (lr / RBR) & (CPR - 1);
+    int offk[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
+    const int arow = (wr * (BM / WR) + lr) * RB, brow = (wc * (BN / WC) + lr) * RB;
+    constexpr int ALO = BM * RB, BLO = BN * RB;     // hi -> lo plane distance inside a slot
+
+    int sa_slot = 0, sb_slot = 0;              // slots the MFMAs consume next
+    constexpr int NM = NJ * (PREC ? 3 : 1);
+    bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const Tile cur = decode(t);
+        f32x16 acc[MI][2];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            // the slots of slab s - 1 are free since the barrier that ended the previous step
+            issueB();
+            ahead = issueA();
+            const unsigned char* sa = smA + sa_slot * ASZ + arow;
+            const unsigned char* sb = smB + sb_slot * BSZ + brow;
+            sa_slot = sa_slot + 1 == NSTA ? 0 : sa_slot + 1;
+            sb_slot = sb_slot + 1 == NSTB ? 0 : sb_slot + 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[0]);
+                if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 32 * RB + offk[0]);
+                bhn[j] = bh[j]; bln[j] = bl[j];
+            }
+            ah = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
+            if (PREC) al = *reinterpret_cast<const bf16x8*>(sa + ALO + offk[0]);
+            ahn = ah; aln = al;
+            __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
+                    if (nks < KS) {
+                        ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 32 * RB + offk[nks < KS ? nks : 0]);
+                        if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + ALO + ni * 32 * RB + offk[nks < KS ? nks : 0]);
+                        if (ni == 0) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) {
+                                bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[nks < KS ? nks : 0]);
+                                if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 32 * RB + offk[nks < KS ? nks : 0]);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (PREC) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    if (nks < KS) {
+                        if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+                    if (nks < KS) {
+                        ah = ahn; al = aln;
+                        if (ni == 0) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) { bh[j] = bhn[j]; bl[j] = bln[j]; }
+                        }
+                    }
+                }
+            // certify the next slab: everything but the far-ahead A slab has landed; everyone is done reading this one
+            if (ahead) wait_vmcnt2<GA>(); else wait_vmcnt2<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        epilogue_vec<MI, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
+    }
+}
+
+// resident workgroups of a kernel on this device (CUs x occupancy)
+template <typename K>
+int ring2_resident_blocks(K kernel, int threads) {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) return 0;
+    return cus * per;
+}
+
+template <int BM, int BN, int BK, int PREC, int WR, int WC>
+void launch_ring2(const GemmArgs& g, hipStream_t st) {
+    static const int resident = ring2_resident_blocks(k_gemm_ring2<BM, BN, BK, PREC, WR, WC>, WR * WC * 64);
+    const int total = g.tiles_m * g.tiles_n * g.d.batch;
+    const int blocks = resident > 0 ? std::min(total, resident) : total;
+    hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
+}
+
+}  // namespace
+
+// configuration ids continue gemm_ring.hip's: 20 / 21 = 256 x 256 split / bf16, 22 / 23 = 192 x 256 split / bf16
+void launch_ring2_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
+    switch (cfg) {
+        case 20: launch_ring2<256, 256, 32, 1, 2, 4>(g, st); break;
+        case 21: launch_ring2<256, 256, 64, 0, 2, 4>(g, st); break;
+        case 22: launch_ring2<192, 256, 32, 1, 2, 4>(g, st); break;
+        case 23: launch_ring2<192, 256, 64, 0, 2, 4>(g, st); break;
+        default: break;
+    }
+}
+
+}  // namespace paa

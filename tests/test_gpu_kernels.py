@@ -210,7 +210,7 @@ def test_gemm_bf16_operands(prec):
 
 
 @pytest.mark.parametrize("prec,cfg", [(0, 2), (0, 3), (0, 5), (0, 8), (0, 12), (0, 14), (0, 15), (1, 4), (1, 6), (1, 7), (1, 11), (1, 13),
-                                      (1, 16), (1, 17), (1, 18), (0, 19)])
+                                      (1, 16), (1, 17), (1, 18), (0, 19), (1, 20), (0, 21), (1, 22), (0, 23)])
 def test_gemm_ring_configurations(prec, cfg):
     """LDS-DMA ring kernels (csrc/gemm_ring.hip) forced through paa_gemm_config: vs the numpy statement of the descriptor
     and BIT-identical to the register-staged kernel (cfg 1) on the same buffers — M / N edges inside the last tiles, a
@@ -235,7 +235,7 @@ def test_gemm_ring_configurations(prec, cfg):
         L.paa_gemm_config(0)
 
 
-@pytest.mark.parametrize("prec,cfg", [(0, 1), (0, 2), (0, 8), (1, 1), (1, 7), (1, 17)])
+@pytest.mark.parametrize("prec,cfg", [(0, 1), (0, 2), (0, 8), (1, 1), (1, 7), (1, 17), (1, 20), (0, 21)])
 def test_gemm_k_group_order(prec, cfg):
     """gemm.h k_group: the K slabs of a strided-conv product walked channel-slab-major / tap-minor (3 taps of 128 channels at
     stride 2 here, and the 2-tap window of a stride-2 dgrad) — same products in another f32 summation order, so the

@@ -12,6 +12,12 @@ from paa_amd import _lib
 
 L = _lib.lib()
 # (name, M, N, K, lda, epilogue) — B=32 x 10 s, wav2vec2-base
+# "pitch" probes: the same products with the A row pitch moved off a multiple of 2 KB (L2 channel spread)
+PITCH = [("pitch conv1 lda1024", 512000, 512, 1536, 1024, "gelu"), ("pitch conv1 lda1088", 512000, 512, 1536, 1088, "gelu"),
+         ("pitch conv1 lda1056", 512000, 512, 1536, 1056, "gelu"),
+         ("pitch ffn2 lda3072", 16000, 768, 3072, 3072, "res"), ("pitch ffn2 lda3136", 16000, 768, 3072, 3136, "res"),
+         ("pitch dqkv lda2304", 16000, 768, 2304, 2304, "res"), ("pitch dqkv lda2368", 16000, 768, 2304, 2368, "res"),
+         ("pitch ffn1 lda768", 16000, 3072, 768, 768, "gelu"), ("pitch ffn1 lda832", 16000, 3072, 768, 832, "gelu")]
 PROBES = [("probe conv1 bf16-out", 512000, 512, 1536, 1024, "bf"), ("probe conv1 bf16-out ALIASED rows", 512000, 512, 1536, 0, "bf"),
           ("probe ffn1 bf16-out", 16000, 3072, 768, None, "bf"), ("probe ffn1 bf16-out ALIASED rows", 16000, 3072, 768, 0, "bf"),
           ("probe sq8192 bf16-out", 8192, 8192, 8192, None, "bf")]
@@ -88,7 +94,7 @@ def timeit(d, iters):
 
 
 def main():
-    cfgs = {0: [1, 2, 8, 19], 1: [1, 7, 17, 18]} if os.environ.get('PAA_SQ_PROBE') else {0: [1, 2, 14, 15], 1: [1, 7, 16]} if os.environ.get('PAA_W4_PROBE') else {0: [1, 2, 8], 1: [1, 4, 17]} if os.environ.get('PAA_KG_PROBE') else {0: [1, 8, 10], 1: [1, 7, 9]} if os.environ.get('PAA_MF16_PROBE') else {0: [1, 8], 1: [1, 7, 13]} if os.environ.get('PAA_DEEP_PROBE') else {0: [1, 2, 3, 5, 8], 1: [1, 4, 6, 7]}
+    cfgs = {0: [2, 21, 19, 23], 1: [17, 20, 18, 22]} if os.environ.get('PAA_R2_PROBE') else {0: [1, 2, 8, 19], 1: [1, 7, 17, 18]} if os.environ.get('PAA_SQ_PROBE') else {0: [1, 2, 14, 15], 1: [1, 7, 16]} if os.environ.get('PAA_W4_PROBE') else {0: [1, 2, 8], 1: [1, 4, 17]} if os.environ.get('PAA_KG_PROBE') else {0: [1, 8, 10], 1: [1, 7, 9]} if os.environ.get('PAA_MF16_PROBE') else {0: [1, 8], 1: [1, 7, 13]} if os.environ.get('PAA_DEEP_PROBE') else {0: [1, 2, 3, 5, 8], 1: [1, 4, 6, 7]}
     argv = sys.argv[1:]
     pick = None
     if "--one" in argv:               # e.g. --one conv1  (profiling runs: one shape family, few launches)
@@ -100,7 +106,7 @@ def main():
     for prec in (0, 1):
         if only and prec not in only:
             continue
-        for (nm, M, N, K, lda, ep) in (PROBES if pick == "probe" else SHAPES):
+        for (nm, M, N, K, lda, ep) in (PROBES if pick == "probe" else PITCH if pick == "pitch" else SHAPES):
             if pick and not (nm == pick if exact else nm.startswith(pick)):
                 continue
             d, outs, keep = build(M, N, K, lda, ep, prec, 512 if nm.endswith(" kg") else 0)
