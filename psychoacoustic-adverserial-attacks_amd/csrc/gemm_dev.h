@@ -234,8 +234,8 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
                 }
                 if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kp[0], kp[1], kp[2], kp[3]);
                 if (Cp16) {
-                    pp[2 * j] = dead ? 0u : (bf16_bits(kp[0]) | ((unsigned)bf16_bits(kp[1]) << 16));
-                    pp[2 * j + 1] = dead ? 0u : (bf16_bits(kp[2]) | ((unsigned)bf16_bits(kp[3]) << 16));
+                    pp[2 * j] = dead ? 0u : bf16_pack2(kp[0], kp[1]);
+                    pp[2 * j + 1] = dead ? 0u : bf16_pack2(kp[2], kp[3]);
                 }
                 if (ex) {
 #pragma unroll
@@ -259,16 +259,12 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
                 }
                 *reinterpret_cast<float4*>(C + ci + 4u * j) = make_float4(x[0], x[1], x[2], x[3]);
             }
-            if (Cb) {
-                unsigned h[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) h[k] = bf16_bits(x[k]);
-                hp[2 * j] = h[0] | (h[1] << 16); hp[2 * j + 1] = h[2] | (h[3] << 16);
+            if (Cb) {                                         // packed conversions: one v_cvt_pk_bf16_f32 per pair and plane
+                const unsigned h01 = bf16_pack2(x[0], x[1]), h23 = bf16_pack2(x[2], x[3]);
+                hp[2 * j] = h01; hp[2 * j + 1] = h23;
                 if (Cbl) {
-                    unsigned l[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) l[k] = bf16_bits(x[k] - __uint_as_float(h[k] << 16));
-                    lp[2 * j] = l[0] | (l[1] << 16); lp[2 * j + 1] = l[2] | (l[3] << 16);
+                    lp[2 * j] = bf16_pack2(x[0] - __uint_as_float(h01 << 16), x[1] - __uint_as_float(h01 & 0xFFFF0000u));
+                    lp[2 * j + 1] = bf16_pack2(x[2] - __uint_as_float(h23 << 16), x[3] - __uint_as_float(h23 & 0xFFFF0000u));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

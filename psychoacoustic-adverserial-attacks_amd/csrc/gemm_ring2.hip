@@ -11,7 +11,9 @@
 // far-ahead A slab stay in flight while B(s + 1) and A(s + 1) are certified for the next step; the one barrier per step also
 // frees the slots the next step refills.  The epilogue's stores sit behind the barrier: they drain under the next step's
 // MFMAs instead of in front of its first wait.  Same fragment layout, swizzle, K order and epilogue as gemm_ring.hip, so
-// results are bit-identical to it.
+// results are bit-identical to it.  Measured (profiles/r2_gemm_ab_sq.txt): +0..5 % per product in isolation, -3.6 % on the
+// whole fp32-parity step.  Tried on top without effect: starting the workgroups of an XCD in four phases a quarter tile
+// apart, so that their epilogues' store bursts do not coincide (every kernel just got slower by the added delay).
 #include <stdlib.h>
 
 #include <algorithm>

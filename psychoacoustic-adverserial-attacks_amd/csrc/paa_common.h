@@ -75,6 +75,12 @@ struct Bf {
 };
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+// two values -> one dword of two bf16 (a in the low half): ONE v_cvt_pk_bf16_f32 on gfx950 (round to nearest even, as bf16_bits)
+__device__ __forceinline__ unsigned bf16_pack2(float a, float b) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{a, b}, b2_t));
+}
 __device__ __forceinline__ void store_bf16(const Bf& o, size_t i, float v) {
     if (o.hi) {
         const unsigned short h = bf16_bits(v);
