@@ -13,7 +13,9 @@
 // MFMAs instead of in front of its first wait.  Same fragment layout, swizzle, K order and epilogue as gemm_ring.hip, so
 // results are bit-identical to it.  Measured (profiles/r2_gemm_ab_sq.txt): +0..5 % per product in isolation, -3.6 % on the
 // whole fp32-parity step.  Tried on top without effect: starting the workgroups of an XCD in four phases a quarter tile
-// apart, so that their epilogues' store bursts do not coincide (every kernel just got slower by the added delay).
+// apart, so that their epilogues' store bursts do not coincide (every kernel just got slower by the added delay); epilogues
+// specialised at compile time for the hot descriptor classes (GELU forward, GELU' backward, f32 result + residual): the first two
+// tie the run-time epilogue, the third is 8..16 % SLOWER per product — the epilogue's cost is not its instruction count.
 #include <stdlib.h>
 
 #include <algorithm>

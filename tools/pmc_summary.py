@@ -32,7 +32,7 @@ def load(d, counter):
 
 def variant_of(kernel: str):
     """PMC kernel name -> the label bench.py's roofline uses for the same launches (None: not a GEMM)."""
-    m = re.search(r"k_gemm_ring<(\d+), (\d+), (\d+), (\d+)", kernel)
+    m = re.search(r"k_gemm_ring2?<(\d+), (\d+), (\d+), (\d+)", kernel)
     if m:
         return f"k_gemm_ring<{m.group(1)},{m.group(2)},{'split' if m.group(4) == '1' else 'bf16'}>"
     m = re.search(r"k_gemm_bf<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>", kernel)
