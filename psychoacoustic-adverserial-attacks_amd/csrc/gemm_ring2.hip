@@ -26,6 +26,10 @@ namespace paa {
 
 namespace {
 
+// 0 (diagnostic builds): every step reads its first fragments at its top instead of under the previous step's last MFMA group
+#ifndef PAA_R2_DEFER
+#define PAA_R2_DEFER 1
+#endif
 typedef __attribute__((address_space(1))) const void* gas_ptr2;
 typedef __attribute__((address_space(3))) void* las_ptr2;
 template <int N>
@@ -43,6 +47,10 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int ASZ = NPL * BM * RB, BSZ = NPL * BN * RB;        // one slot of each ring: hi rows [| lo rows]
     constexpr int GA = NPL * BM / RPI / NW, GB = NPL * BN / RPI / NW;   // DMA wave-instructions per wave per slab
     constexpr int MI = BM / WR / 32, NJ = BN / WC / 32, KS = BK / 16;
+    // split mode only: the last MFMA group of a K slab runs AFTER the certifying barrier, over the reads of the next slab's first
+    // fragments (+0..4 % per product; in bf16 mode a group is two MFMAs — too short to cover an LDS round trip — and the form
+    // measured -3..+1 %)
+    constexpr bool DEFER = PAA_R2_DEFER && PREC;
     static_assert(NJ == 2, "vector epilogue: 64 columns per wave");
     static_assert((NPL * BM) % (RPI * NW) == 0 && (NPL * BN) % (RPI * NW) == 0 && BM % RPI == 0 && BN % RPI == 0, "a DMA wave-instruction must not straddle planes");
     static_assert(NSTA * ASZ + NSTB * BSZ <= 160 * 1024 && GA + GB < 32, "rings do not fit");
@@ -158,6 +166,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     int sa_slot = 0, sb_slot = 0;              // slots the MFMAs consume next
     constexpr int NM = NJ * (PREC ? 3 : 1);
     bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
+    bool have_first = false;                   // the coming slab's first fragments are already in the "next" registers
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const Tile cur = decode(t);
         f32x16 acc[MI][2];
@@ -176,16 +185,21 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
             const unsigned char* sb = smB + sb_slot * BSZ + brow;
             sa_slot = sa_slot + 1 == NSTA ? 0 : sa_slot + 1;
             sb_slot = sb_slot + 1 == NSTB ? 0 : sb_slot + 1;
+            const bool last = kt + 1 == nk;
+            if (!(DEFER && have_first)) {          // first fragments of this slab (else: read under the previous slab's last MFMAs)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[0]);
-                if (PREC) bl[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 32 * RB + offk[0]);
-                bhn[j] = bh[j]; bln[j] = bl[j];
+                for (int j = 0; j < NJ; ++j) {
+                    bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[0]);
+                    if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 32 * RB + offk[0]);
+                }
+                ahn = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
+                if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + ALO + offk[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
             }
-            ah = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
-            if (PREC) al = *reinterpret_cast<const bf16x8*>(sa + ALO + offk[0]);
-            ahn = ah; aln = al;
-            __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { bh[j] = bhn[j]; bl[j] = bln[j]; }
+            ah = ahn; al = aln;
+            have_first = false;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -201,6 +215,25 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                                 if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 32 * RB + offk[nks < KS ? nks : 0]);
                             }
                         }
+                    } else if (DEFER && !last) {
+                        // last MFMA group of the slab (its fragments are in registers): certify the next slab FIRST and read its
+                        // first fragments under these MFMAs, instead of paying an LDS round trip with all eight waves at the top
+                        // of the next step.  (Not across a tile boundary: the fragments would stay live over the epilogue.)
+                        if (ahead) wait_vmcnt2<GA>(); else wait_vmcnt2<0>();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my last fragment reads of this slab have returned: its slots may be refilled
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        const unsigned char* san = smA + sa_slot * ASZ + arow;
+                        const unsigned char* sbn = smB + sb_slot * BSZ + brow;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            bhn[j] = *reinterpret_cast<const bf16x8*>(sbn + j * 32 * RB + offk[0]);
+                            if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sbn + BLO + j * 32 * RB + offk[0]);
+                        }
+                        ahn = *reinterpret_cast<const bf16x8*>(san + offk[0]);
+                        if (PREC) aln = *reinterpret_cast<const bf16x8*>(san + ALO + offk[0]);
+                        have_first = true;
                     }
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -215,6 +248,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                     if (nks < KS) {
                         if (ni == 0) __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
                         else __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+                    } else if (DEFER && !last) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
                     if (nks < KS) {
@@ -225,11 +260,13 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                         }
                     }
                 }
-            // certify the next slab: everything but the far-ahead A slab has landed; everyone is done reading this one
-            if (ahead) wait_vmcnt2<GA>(); else wait_vmcnt2<0>();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            if (!DEFER || last) {
+                // certify the next slab: everything but the far-ahead A slab has landed; everyone is done reading this one
+                if (ahead) wait_vmcnt2<GA>(); else wait_vmcnt2<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         epilogue_vec<MI, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
     }
