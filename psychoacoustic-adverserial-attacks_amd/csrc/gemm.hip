@@ -620,6 +620,22 @@ bool ring_cfg_ok(int cfg, const paa_gemm_desc& d);
 // Ring-kernel selection (paa_gemm_config): 0 = automatic, 1 = never (the register-staged kernels of round 1),
 // 2.. = force one ring configuration where its shape constraints hold (kernel A/B runs in tools/gemm_bench.py).
 static int g_ring_mode = 0;
+// A/B switches of the selection, read from the environment at the first product and again by every paa_gemm_config call
+// (tools/step_ab.py sets the variables, then calls it): PAA_NO_SQ=1 no 256-column rings, PAA_NO_R2=1 their two-stage form
+// instead of the separate operand rings, PAA_K_GROUP=0 plain K order in the strided convs (gemm_env_kgroup, used by model.hip).
+struct GemmEnv { bool init = false, no_sq = false, no_r2 = false, kgroup = true; };
+static GemmEnv g_env;
+static void gemm_env_refresh() {
+    auto on = [](const char* name, char v) { const char* e = getenv(name); return e && e[0] == v; };
+    g_env.no_sq = on("PAA_NO_SQ", '1');
+    g_env.no_r2 = on("PAA_NO_R2", '1');
+    g_env.kgroup = !on("PAA_K_GROUP", '0');
+    g_env.init = true;
+}
+bool gemm_env_kgroup() {
+    if (!g_env.init) gemm_env_refresh();
+    return g_env.kgroup;
+}
 
 template <int BN, int PREC>
 static void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
@@ -691,8 +707,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         // two workgroups per CU win wherever 256-row tiles leave the persistent grid's last round part-empty (N = 768:
         // 378 tiles on 256 slots, +15..22 % split, +5..10 % bf16; N = 2304: +3..10 %); everywhere else the ring kernels
         // only tie the register-staged ones (within 3 %), which stay the default.
-        const char* nsq = getenv("PAA_NO_SQ");           // A/B measurements (read per call): automatic selection without the 256 x 256 rings
-        const bool no_sq = nsq && nsq[0] == '1';
+        if (!g_env.init) gemm_env_refresh();
+        const bool no_sq = g_env.no_sq;                  // A/B measurements: automatic selection without the 256-column rings
         if (g_ring_mode >= 2) ring = g_ring_mode;
         else if (d.precision) {
             const int64_t slots = 256;
@@ -731,11 +747,10 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             if (rsq <= r2) ring = 2;      // a round is one 256 x 256 tile or two co-resident 256 x 128 tiles per CU: equal work
         }
         // separate operand rings (gemm_ring2.hip: three A slots, two B slots) for the 256-column tiles: +0..5 % per product over the
-        // two-stage rings; PAA_NO_R2=1 (A/B measurements, read per call) keeps the two-stage forms
+        // two-stage rings; PAA_NO_R2=1 (A/B measurements) keeps the two-stage forms
         if (g_ring_mode < 2 && (ring == 17 || ring == 2 || ring == 18 || ring == 19)) {
-            const char* nr2 = getenv("PAA_NO_R2");
             const int r2 = ring == 17 ? 20 : ring == 2 ? 21 : ring == 18 ? 22 : 23;
-            if (!(nr2 && nr2[0] == '1') && ring_cfg_ok(r2, d)) ring = r2;
+            if (!g_env.no_r2 && ring_cfg_ok(r2, d)) ring = r2;
         }
         if (ring == 13) { if (!d.precision) ring = 0; }          // 13: register-staged 192 x 128 split tile, swizzled LDS, two workgroups per CU
         else if (ring && !ring_cfg_ok(ring, d)) ring = 0;
@@ -862,7 +877,7 @@ extern "C" paa_status paa_prof_pause(int paused) {
     return PAA_OK;
 }
 
-extern "C" void paa_gemm_config(int ring_mode) { paa::g_ring_mode = ring_mode; }
+extern "C" void paa_gemm_config(int ring_mode) { paa::g_ring_mode = ring_mode; paa::gemm_env_refresh(); }
 
 extern "C" paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream) {
     if (!d) { paa::set_error("paa_gemm: null descriptor"); return PAA_ERR_ARG; }

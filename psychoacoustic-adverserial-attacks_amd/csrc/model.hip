@@ -329,8 +329,10 @@ static paa_gemm_desc gd(const paa_model* m, const float* A, const float* Bm, flo
     d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;
     return d;
 }
-// PAA_K_GROUP=0 (A/B measurements, read per call): plain K order in the strided-conv products instead of gemm.h's k_group order
-static bool kgroup_on() { const char* e = getenv("PAA_K_GROUP"); return !(e && e[0] == '0'); }
+// PAA_K_GROUP=0 (A/B measurements; gemm.hip caches the environment): plain K order in the strided-conv products instead of gemm.h's
+// k_group order
+namespace paa { bool gemm_env_kgroup(); }
+static bool kgroup_on() { return paa::gemm_env_kgroup(); }
 // bf16-operand descriptor (every conv / linear product)
 static paa_gemm_desc gdb(const paa_model* m, CBf A, CBf W, float* C, Bf Cb, int M, int N, int K, int64_t lda, int64_t ldb,
                          int64_t ldc) {
