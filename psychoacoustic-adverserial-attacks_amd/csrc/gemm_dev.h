@@ -8,7 +8,6 @@ namespace paa {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G_BM = 128, G_BK = 32, G_LD = 40 /* bf16 per LDS row */, G_NT = 256;
 
@@ -277,159 +276,5 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
         }
     }
 }
-
-// The same epilogue for accumulators of v_mfma_f32_16x16x32_bf16 issued as mfma(B fragment, A fragment): lane l then holds output
-// row l & 15 of each 16-row tile and columns 4 (l >> 4) + r of each 16-column tile; with the B rows of a 64-column group permuted
-// so that LDS row 16 j + 4 g + r carries logical column 16 g + 4 j + r (gemm_ring2.hip), the 16 values acc[i][0..3][0..3] of a lane
-// are 16 CONSECUTIVE columns of one row: two 8-column units per 16-row tile, no cross-lane transposes at all.
-template <int TM, bool FAST>
-__device__ __forceinline__ void epilogue_vec16(const paa_gemm_desc& d, f32x4 (&acc)[TM][4], int m0w, int n0w, int z1, int z2, int lane) {
-    const int col0 = n0w + 16 * (lane >> 4);            // this lane's 16 columns: units u = (i, h) cover col0 + 8 h ..
-    const int row0 = m0w + (lane & 15);                 // + 16 i
-    const bool col_ok0 = col0 < d.N, col_ok1 = col0 + 8 < d.N;
-    const int act = d.act;
-    const bool gg = act == PAA_ACT_GELU_GRAD;
-    const int64_t cbase = z1 * d.c_s1 + z2 * d.c_s2;
-    float* __restrict__ C = d.C ? d.C + cbase : nullptr;
-    const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored as bf16
-    const bool gate = d.aux_gate != 0;                  // C_pre / aux hold gelu'(v)
-    float* __restrict__ Cp = (d.C_pre && !x16) ? d.C_pre + cbase : nullptr;
-    unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + cbase : nullptr;
-    unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + cbase : nullptr;
-    unsigned short* __restrict__ Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + cbase : nullptr;
-    const bool ex16 = gg && x16;                        // the extra stream is bf16: 8 columns = one 16-byte vector
-    const float* __restrict__ ex = gg ? (ex16 ? nullptr : d.aux + z1 * d.aux_s1 + z2 * d.aux_s2)
-                                      : (d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr);
-    const unsigned short* __restrict__ exh = ex16 ? reinterpret_cast<const unsigned short*>(d.aux) + z1 * d.aux_s1 + z2 * d.aux_s2 : nullptr;
-    const unsigned ldc = (unsigned)d.ldc, ldx = (unsigned)(gg ? d.ld_aux : d.ld_res);
-    const unsigned co = (unsigned)row0 * ldc + (unsigned)col0;
-    const unsigned xo = (unsigned)row0 * ldx + (unsigned)col0;
-    float bv[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) bv[k] = 0.f;
-    if (d.bias) {
-        const float* bp = d.bias + z2 * d.bias_s2;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (h ? col_ok1 : col_ok0) {
-                const float4 b0 = *reinterpret_cast<const float4*>(bp + (unsigned)col0 + 8u * h);
-                const float4 b1 = *reinterpret_cast<const float4*>(bp + (unsigned)col0 + 8u * h + 4u);
-                bv[8 * h] = b0.x; bv[8 * h + 1] = b0.y; bv[8 * h + 2] = b0.z; bv[8 * h + 3] = b0.w;
-                bv[8 * h + 4] = b1.x; bv[8 * h + 5] = b1.y; bv[8 * h + 6] = b1.z; bv[8 * h + 7] = b1.w;
-            }
-    }
-    const int period = d.row_period;
-    const int mrem0 = period > 0 ? row0 % period : 0;
-    const float alpha = d.alpha;
-    const bool accum = d.accumulate != 0;
-    constexpr int NG = 2 * TM;                           // units: (16-row tile i, 8-column half h)
-    uint4 xv[2][2];                                       // raw bits: 2 x float4, or one uint4 of 8 bf16 in [0]
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { xv[u][0] = make_uint4(0u, 0u, 0u, 0u); xv[u][1] = xv[u][0]; }
-    auto fetch = [&](int grp, uint4 (&v2)[2]) {
-        const int dm = (grp >> 1) * 16, hh = grp & 1;
-        if ((hh ? col_ok1 : col_ok0) && row0 + dm < d.M) {
-            const unsigned o = xo + (unsigned)dm * ldx + 8u * hh;
-            if (ex) {
-                v2[0] = *reinterpret_cast<const uint4*>(ex + o);
-                v2[1] = *reinterpret_cast<const uint4*>(ex + o + 4u);
-            } else if (exh) {
-                v2[0] = *reinterpret_cast<const uint4*>(exh + o);
-            }
-        }
-    };
-    fetch(0, xv[0]);
-#pragma unroll
-    for (int grp = 0; grp < NG; ++grp) {
-        const int i = grp >> 1, hh = grp & 1, u = grp & 1;
-        if (grp + 1 < NG) fetch(grp + 1, xv[u ^ 1]);
-        const int dm = i * 16;
-        const bool live = (hh ? col_ok1 : col_ok0) && row0 + dm < d.M;
-        bool dead = false;
-        if (period > 0) {
-            int rem = mrem0 + dm;
-            if (rem >= period) rem = (period >= 256) ? rem - period : rem % period;
-            dead = rem >= d.row_valid;
-        }
-        const unsigned ci = co + (unsigned)dm * ldc + 8u * hh;
-        unsigned hp[4], lp[4], pp[4];                        // packed bf16 pairs of the 8 columns (result hi / lo, C_pre)
-        // the two 4-column halves go through the math one after the other: with the tile's 64 accumulator registers
-        // still live there is no room for eight interleaved GELU chains
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float x[4] = {acc[i][2 * hh + j][0], acc[i][2 * hh + j][1], acc[i][2 * hh + j][2], acc[i][2 * hh + j][3]};
-            float e4[4];
-            if (ex16) {
-                const unsigned w0 = j ? xv[u][0].z : xv[u][0].x, w1 = j ? xv[u][0].w : xv[u][0].y;
-                e4[0] = __uint_as_float(w0 << 16); e4[1] = __uint_as_float(w0 & 0xFFFF0000u);
-                e4[2] = __uint_as_float(w1 << 16); e4[3] = __uint_as_float(w1 & 0xFFFF0000u);
-            } else {
-                e4[0] = __uint_as_float(xv[u][j].x); e4[1] = __uint_as_float(xv[u][j].y);
-                e4[2] = __uint_as_float(xv[u][j].z); e4[3] = __uint_as_float(xv[u][j].w);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = x[k] * alpha + bv[8 * hh + 4 * j + k];
-            if (act == PAA_ACT_GELU) {
-                float kp[4];                                  // what the backward pass will want: v, or gelu'(v) (aux_gate)
-                if (FAST) {                                   // two values per packed-math GELU
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        f32x2 dg;
-                        const f32x2 gv = gelu_both_fast2(f32x2{x[k], x[k + 1]}, dg);
-                        kp[k] = gate ? dg.x : x[k]; kp[k + 1] = gate ? dg.y : x[k + 1];
-                        x[k] = gv.x; x[k + 1] = gv.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        kp[k] = gate ? gelu_grad_f(x[k]) : x[k];
-                        x[k] = gelu_f(x[k]);
-                    }
-                }
-                if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kp[0], kp[1], kp[2], kp[3]);
-                if (Cp16) {
-                    pp[2 * j] = dead ? 0u : bf16_pack2(kp[0], kp[1]);
-                    pp[2 * j + 1] = dead ? 0u : bf16_pack2(kp[2], kp[3]);
-                }
-                if (ex) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) x[k] += e4[k];
-                }
-            } else if (gg) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] *= gate ? e4[k] : (FAST ? gelu_grad_fast(e4[k]) : gelu_grad_f(e4[k]));
-            } else if (ex) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] += e4[k];
-            }
-            if (dead) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = 0.f;
-            }
-            if (C && live) {
-                if (accum) {
-                    const float4 c0 = *reinterpret_cast<const float4*>(C + ci + 4u * j);
-                    x[0] += c0.x; x[1] += c0.y; x[2] += c0.z; x[3] += c0.w;
-                }
-                *reinterpret_cast<float4*>(C + ci + 4u * j) = make_float4(x[0], x[1], x[2], x[3]);
-            }
-            if (Cb) {                                         // packed conversions: one v_cvt_pk_bf16_f32 per pair and plane
-                const unsigned h01 = bf16_pack2(x[0], x[1]), h23 = bf16_pack2(x[2], x[3]);
-                hp[2 * j] = h01; hp[2 * j + 1] = h23;
-                if (Cbl) {
-                    lp[2 * j] = bf16_pack2(x[0] - __uint_as_float(h01 << 16), x[1] - __uint_as_float(h01 & 0xFFFF0000u));
-                    lp[2 * j + 1] = bf16_pack2(x[2] - __uint_as_float(h23 << 16), x[3] - __uint_as_float(h23 & 0xFFFF0000u));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (Cp16 && live && act == PAA_ACT_GELU) *reinterpret_cast<uint4*>(Cp16 + ci) = make_uint4(pp[0], pp[1], pp[2], pp[3]);
-        if (Cb && live) {
-            *reinterpret_cast<uint4*>(Cb + ci) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-            if (Cbl) *reinterpret_cast<uint4*>(Cbl + ci) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
-        }
-    }
-}
-
 
 }  // namespace paa

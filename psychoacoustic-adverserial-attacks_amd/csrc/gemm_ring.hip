@@ -366,16 +366,16 @@ extern "C" double paa_debug_ring_clock_ghz(int n_blocks) {
 namespace paa {
 #endif
 
-int ring_tile_rows(int cfg) { return ((cfg >= 7 && cfg <= 13) || cfg == 18 || cfg == 19 || cfg == 22 || cfg == 23 || cfg == 26 || cfg == 27) ? 192 : 256; }
+int ring_tile_rows(int cfg) { return ((cfg >= 7 && cfg <= 13) || cfg == 18 || cfg == 19 || cfg == 22 || cfg == 23) ? 192 : 256; }
 int ring_tile_cols(int cfg) { return (cfg == 4 || (cfg >= 6 && cfg <= 13)) ? 128 : 256; }
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
-    if (cfg < 2 || cfg > 27 || cfg == 13) return false;       // 20..27: gemm_ring2.hip (separate operand rings)
+    if (cfg < 2 || cfg > 23 || cfg == 13) return false;       // 20..23: gemm_ring2.hip (separate operand rings)
     // 9 / 10 are timing probes with WRONG results (MF16): only reachable when the measurement script asks for them
     static const bool probes = getenv("PAA_MF16_PROBE") != nullptr;
     if ((cfg == 9 || cfg == 10) && !probes) return false;
-    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 20 || cfg == 22 || cfg == 24 || cfg == 26;
+    const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 20 || cfg == 22;
     if (split != (d.precision != 0)) return false;
-    const int bk = (cfg == 2 || cfg == 8 || cfg == 10 || cfg == 14 || cfg == 19 || cfg == 21 || cfg == 23 || cfg == 25 || cfg == 27) ? 64 : cfg == 11 ? 16 : 32;
+    const int bk = (cfg == 2 || cfg == 8 || cfg == 10 || cfg == 14 || cfg == 19 || cfg == 21 || cfg == 23) ? 64 : cfg == 11 ? 16 : 32;
     return d.K % bk == 0 && d.K >= 4 * bk;
 }
 

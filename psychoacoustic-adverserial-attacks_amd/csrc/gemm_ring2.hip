@@ -35,10 +35,7 @@ typedef __attribute__((address_space(3))) void* las_ptr2;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt2() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// MF16: the products run as v_mfma_f32_16x16x32_bf16 (operands swapped, so a lane ends up with one output row and 16 consecutive
-// columns per 16-row tile: epilogue_vec16, no cross-lane transposes) instead of v_mfma_f32_32x32x16_bf16: same LDS traffic and MFMA
-// cycles, but the 16x16 shape holds a higher clock inside these loops and its epilogue is shorter.
-template <int BM, int BN, int BK, int PREC, int WR, int WC, bool MF16 = false>
+template <int BM, int BN, int BK, int PREC, int WR, int WC>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int NW = WR * WC;
     constexpr int NPL = PREC ? 2 : 1;
@@ -53,7 +50,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     // split mode only: the last MFMA group of a K slab runs AFTER the certifying barrier, over the reads of the next slab's first
     // fragments (+0..4 % per product; in bf16 mode a group is two MFMAs — too short to cover an LDS round trip — and the form
     // measured -3..+1 %)
-    constexpr bool DEFER = PAA_R2_DEFER && PREC && !MF16;
+    constexpr bool DEFER = PAA_R2_DEFER && PREC;
     static_assert(NJ == 2, "vector epilogue: 64 columns per wave");
     static_assert((NPL * BM) % (RPI * NW) == 0 && (NPL * BN) % (RPI * NW) == 0 && BM % RPI == 0 && BN % RPI == 0, "a DMA wave-instruction must not straddle planes");
     static_assert(NSTA * ASZ + NSTB * BSZ <= 160 * 1024 && GA + GB < 32, "rings do not fit");
@@ -127,8 +124,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
             const int pl = r / BN, p = r - pl * BN;
             const int ch = (lane % CPR) ^ ((p / RBR) & (CPR - 1));
             const unsigned short* B = reinterpret_cast<const unsigned short*>(pl ? d.B_lo : (const void*)d.B) + boff;
-            const int nl = MF16 ? (p & ~63) + 16 * ((p & 15) >> 2) + 4 * ((p >> 4) & 3) + (p & 3)      // LDS row 16 j + 4 g + r <- column 16 g + 4 j + r
-                                : (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);   // row permutation of the vector epilogue
+            const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);      // row permutation of the vector epilogue
             srcB[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
         }
     };
@@ -171,71 +167,6 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int NM = NJ * (PREC ? 3 : 1);
     bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
     bool have_first = false;                   // the coming slab's first fragments are already in the "next" registers
-    if constexpr (MF16) {
-        // ---- 16x16x32 form: TM 16-row tiles x four 16-column tiles per wave, one k step of 32 per 64-byte row (two per 128-byte row)
-        constexpr int TM = BM / WR / 16, K32 = BK / 32;
-        const int l15 = lane & 15, lq = lane >> 4;
-        const int sw16 = (l15 / RBR) & (CPR - 1);
-        int off16[K32];
-#pragma unroll
-        for (int ks = 0; ks < K32; ++ks) off16[ks] = ((lq + 4 * ks) ^ sw16) << 4;
-        const int arow16 = (wr * (BM / WR) + l15) * RB, brow16 = (wc * (BN / WC) + l15) * RB;
-        bf16x8 qh[4], ql[4], xh, xl, xhn, xln;          // B fragments of the four column tiles; A fragment of a row tile (current / next)
-        for (int t = blockIdx.x; t < total; t += gridDim.x) {
-            const Tile cur = decode(t);
-            f32x4 acc[TM][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-            for (int kt = 0; kt < nk; ++kt) {
-                issueB();
-                ahead = issueA();
-                const unsigned char* sa = smA + sa_slot * ASZ + arow16;
-                const unsigned char* sb = smB + sb_slot * BSZ + brow16;
-                sa_slot = sa_slot + 1 == NSTA ? 0 : sa_slot + 1;
-                sb_slot = sb_slot + 1 == NSTB ? 0 : sb_slot + 1;
-#pragma unroll
-                for (int ks = 0; ks < K32; ++ks) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        qh[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * RB + off16[ks]);
-                        if (PREC) ql[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 16 * RB + off16[ks]);
-                    }
-                    xhn = *reinterpret_cast<const bf16x8*>(sa + off16[ks]);
-                    if (PREC) xln = *reinterpret_cast<const bf16x8*>(sa + ALO + off16[ks]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 5 * NPL, 0);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        xh = xhn; xl = xln;
-                        if (i + 1 < TM) {
-                            xhn = *reinterpret_cast<const bf16x8*>(sa + (i + 1) * 16 * RB + off16[ks]);
-                            if (PREC) xln = *reinterpret_cast<const bf16x8*>(sa + ALO + (i + 1) * 16 * RB + off16[ks]);
-                        }
-                        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (PREC) {
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], xl, acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[j], xh, acc[i][j], 0, 0, 0);
-                            }
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], xh, acc[i][j], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_s_setprio(0);
-                        if (i + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 4 * (PREC ? 3 : 1), 0);
-                    }
-                }
-                if (ahead) wait_vmcnt2<GA>(); else wait_vmcnt2<0>();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            epilogue_vec16<TM, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
-        }
-    } else {
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const Tile cur = decode(t);
         f32x16 acc[MI][2];
@@ -339,7 +270,6 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         }
         epilogue_vec<MI, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
     }
-    }
 }
 
 // resident workgroups of a kernel on this device (CUs x occupancy)
@@ -352,28 +282,23 @@ int ring2_resident_blocks(K kernel, int threads) {
     return cus * per;
 }
 
-template <int BM, int BN, int BK, int PREC, int WR, int WC, bool MF16 = false>
+template <int BM, int BN, int BK, int PREC, int WR, int WC>
 void launch_ring2(const GemmArgs& g, hipStream_t st) {
-    static const int resident = ring2_resident_blocks(k_gemm_ring2<BM, BN, BK, PREC, WR, WC, MF16>, WR * WC * 64);
+    static const int resident = ring2_resident_blocks(k_gemm_ring2<BM, BN, BK, PREC, WR, WC>, WR * WC * 64);
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
-    hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC, MF16>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
+    hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
 }
 
 }  // namespace
 
-// configuration ids continue gemm_ring.hip's: 20 / 21 = 256 x 256 split / bf16, 22 / 23 = 192 x 256 split / bf16, 24..27 = the same
-// four with 16x16x32 MFMAs
+// configuration ids continue gemm_ring.hip's: 20 / 21 = 256 x 256 split / bf16, 22 / 23 = 192 x 256 split / bf16
 void launch_ring2_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
     switch (cfg) {
         case 20: launch_ring2<256, 256, 32, 1, 2, 4>(g, st); break;
         case 21: launch_ring2<256, 256, 64, 0, 2, 4>(g, st); break;
         case 22: launch_ring2<192, 256, 32, 1, 2, 4>(g, st); break;
         case 23: launch_ring2<192, 256, 64, 0, 2, 4>(g, st); break;
-        case 24: launch_ring2<256, 256, 32, 1, 2, 4, true>(g, st); break;     // 20 / 21 / 22 / 23 with 16x16x32 MFMAs
-        case 25: launch_ring2<256, 256, 64, 0, 2, 4, true>(g, st); break;
-        case 26: launch_ring2<192, 256, 32, 1, 2, 4, true>(g, st); break;
-        case 27: launch_ring2<192, 256, 64, 0, 2, 4, true>(g, st); break;
         default: break;
     }
 }

@@ -235,23 +235,6 @@ def test_gemm_ring_configurations(prec, cfg):
         L.paa_gemm_config(0)
 
 
-@pytest.mark.parametrize("prec,cfg", [(1, 24), (0, 25), (1, 26), (0, 27)])
-def test_gemm_ring_mfma16(prec, cfg):
-    """gemm_ring2.hip with v_mfma_f32_16x16x32_bf16 (operands swapped, epilogue_vec16): another f32 summation order inside a K slab,
-    so checked against the numpy statement of the descriptor (same cases and tolerances as the bit-compared ring configurations)."""
-    L = _lib.lib()
-    try:
-        L.paa_gemm_config(cfg)
-        _bf_case(f"mf16_gelu/cfg{cfg}", dict(M=2200, N=640, K=320, lda=320, ldb=320, ldc=640, alpha=0.5, act=1),
-                 dict(A=2200 * 320, B=640 * 320, C=2200 * 640, bias=640, C_pre=2200 * 640), prec, seed=7, x16=prec == 0, gate=True)
-        _bf_case(f"mf16_resid/cfg{cfg}", dict(M=2304, N=768, K=768, lda=768, ldb=768, ldc=768, ld_res=768),
-                 dict(A=2304 * 768, B=768 * 768, C=2304 * 768, residual=2304 * 768), prec, seed=7)
-        _bf_case(f"mf16_convview/cfg{cfg}", dict(M=4000, N=512, K=384, lda=256, ldb=384, ldc=512, row_period=500, row_valid=499, act=2, ld_aux=512, k_group=128),
-                 dict(A=(2 * 4000 + 8) * 128, B=512 * 384, C=4000 * 512, aux=4000 * 512), prec, seed=7, x16=prec == 0, gate=True)
-    finally:
-        L.paa_gemm_config(0)
-
-
 @pytest.mark.parametrize("prec,cfg", [(0, 1), (0, 2), (0, 8), (1, 1), (1, 7), (1, 17), (1, 20), (0, 21)])
 def test_gemm_k_group_order(prec, cfg):
     """gemm.h k_group: the K slabs of a strided-conv product walked channel-slab-major / tap-minor (3 taps of 128 channels at

@@ -94,7 +94,7 @@ def timeit(d, iters):
 
 
 def main():
-    cfgs = {0: [21, 25, 23, 27], 1: [20, 24, 22, 26]} if os.environ.get('PAA_MF_PROBE') else {0: [2, 21, 19, 23], 1: [17, 20, 18, 22]} if os.environ.get('PAA_R2_PROBE') else {0: [1, 2, 8, 19], 1: [1, 7, 17, 18]} if os.environ.get('PAA_SQ_PROBE') else {0: [1, 2, 14, 15], 1: [1, 7, 16]} if os.environ.get('PAA_W4_PROBE') else {0: [1, 2, 8], 1: [1, 4, 17]} if os.environ.get('PAA_KG_PROBE') else {0: [1, 8, 10], 1: [1, 7, 9]} if os.environ.get('PAA_MF16_PROBE') else {0: [1, 8], 1: [1, 7, 13]} if os.environ.get('PAA_DEEP_PROBE') else {0: [1, 2, 3, 5, 8], 1: [1, 4, 6, 7]}
+    cfgs = {0: [2, 21, 19, 23], 1: [17, 20, 18, 22]} if os.environ.get('PAA_R2_PROBE') else {0: [1, 2, 8, 19], 1: [1, 7, 17, 18]} if os.environ.get('PAA_SQ_PROBE') else {0: [1, 2, 14, 15], 1: [1, 7, 16]} if os.environ.get('PAA_W4_PROBE') else {0: [1, 2, 8], 1: [1, 4, 17]} if os.environ.get('PAA_KG_PROBE') else {0: [1, 8, 10], 1: [1, 7, 9]} if os.environ.get('PAA_MF16_PROBE') else {0: [1, 8], 1: [1, 7, 13]} if os.environ.get('PAA_DEEP_PROBE') else {0: [1, 2, 3, 5, 8], 1: [1, 4, 6, 7]}
     argv = sys.argv[1:]
     pick = None
     if "--one" in argv:               # e.g. --one conv1  (profiling runs: one shape family, few launches)
