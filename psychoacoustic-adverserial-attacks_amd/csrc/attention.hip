@@ -68,17 +68,19 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned short* rm, int lr, int 
     return r;
 }
 // bf16 pack of accumulator registers 8 s2 .. 8 s2 + 7 (the B operand of the follow-up product)
+// (pairs go through one v_cvt_pk_bf16_f32 each: bf16_pack2, paa_common.h)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[16], int s2) {
-    bf16x8 r;
+    u32x4 r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (short)bf16_bits(v[8 * s2 + j]);
-    return r;
+    for (int j = 0; j < 4; ++j) r[j] = bf16_pack2(v[8 * s2 + 2 * j], v[8 * s2 + 2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ bf16x8 pack8v(const f32x16& v, int s2) {
-    bf16x8 r;
+    u32x4 r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (short)bf16_bits(v[8 * s2 + j]);
-    return r;
+    for (int j = 0; j < 4; ++j) r[j] = bf16_pack2(v[8 * s2 + 2 * j], v[8 * s2 + 2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, r);
 }
 // own-position operand fragments (B operand of X = other x own): 16 B at row `own`, k = 16s + 8lh
 __device__ __forceinline__ void load_own(const unsigned short* __restrict__ src, int64_t ld, int row, int lh, bf16x8 (&f)[4]) {
@@ -93,8 +95,8 @@ __device__ __forceinline__ void store_own(unsigned short* __restrict__ dst, int6
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = dt * 32 + 8 * g4 + 4 * lh;
-            const unsigned a = bf16_bits(acc[dt][4 * g4] * mul) | ((unsigned)bf16_bits(acc[dt][4 * g4 + 1] * mul) << 16);
-            const unsigned b = bf16_bits(acc[dt][4 * g4 + 2] * mul) | ((unsigned)bf16_bits(acc[dt][4 * g4 + 3] * mul) << 16);
+            const unsigned a = bf16_pack2(acc[dt][4 * g4] * mul, acc[dt][4 * g4 + 1] * mul);
+            const unsigned b = bf16_pack2(acc[dt][4 * g4 + 2] * mul, acc[dt][4 * g4 + 3] * mul);
             *reinterpret_cast<uint2*>(dst + (int64_t)row * ld + d) = make_uint2(a, b);
         }
 }
@@ -129,12 +131,15 @@ __device__ __forceinline__ f32x16 mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 b
 // bf16 hi (and lo = bf16(v - hi)) packs of accumulator registers 8 s2 .. 8 s2 + 7
 template <int PREC, typename V>
 __device__ __forceinline__ void pack8s(const V& v, int s2, bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const unsigned short h = bf16_bits(v[8 * s2 + j]);
-        hi[j] = (short)h;
-        if constexpr (PREC) lo[j] = (short)bf16_bits(v[8 * s2 + j] - bf16_to_f32(h));
+    for (int j = 0; j < 4; ++j) {
+        const float a = v[8 * s2 + 2 * j], b = v[8 * s2 + 2 * j + 1];
+        h[j] = bf16_pack2(a, b);
+        if constexpr (PREC) l[j] = bf16_pack2(a - __uint_as_float(h[j] << 16), b - __uint_as_float(h[j] & 0xFFFF0000u));
     }
+    hi = __builtin_bit_cast(bf16x8, h);
+    if constexpr (PREC) lo = __builtin_bit_cast(bf16x8, l);
 }
 // write the transposed accumulators acc[dt][e] * mul as bf16 rows into the hi (and lo) plane
 template <int PREC>
@@ -145,15 +150,13 @@ __device__ __forceinline__ void store_own_s(unsigned short* __restrict__ dh, uns
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = dt * 32 + 8 * g4 + 4 * lh;
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = acc[dt][4 * g4 + k] * mul;
-                h[k] = bf16_bits(v);
-                l[k] = PREC ? bf16_bits(v - __uint_as_float(h[k] << 16)) : 0u;
-            }
-            *reinterpret_cast<uint2*>(dh + (int64_t)row * ld + d) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-            if constexpr (PREC) *reinterpret_cast<uint2*>(dl + (int64_t)row * ld + d) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            const float v0 = acc[dt][4 * g4] * mul, v1 = acc[dt][4 * g4 + 1] * mul, v2 = acc[dt][4 * g4 + 2] * mul, v3 = acc[dt][4 * g4 + 3] * mul;
+            const unsigned h01 = bf16_pack2(v0, v1), h23 = bf16_pack2(v2, v3);
+            *reinterpret_cast<uint2*>(dh + (int64_t)row * ld + d) = make_uint2(h01, h23);
+            if constexpr (PREC)
+                *reinterpret_cast<uint2*>(dl + (int64_t)row * ld + d) =
+                    make_uint2(bf16_pack2(v0 - __uint_as_float(h01 << 16), v1 - __uint_as_float(h01 & 0xFFFF0000u)),
+                               bf16_pack2(v2 - __uint_as_float(h23 << 16), v3 - __uint_as_float(h23 & 0xFFFF0000u)));
         }
 }
 
