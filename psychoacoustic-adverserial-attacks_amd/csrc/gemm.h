@@ -74,6 +74,11 @@ typedef struct paa_gemm_desc {
     // left L2 by then, tap-minor they are adjacent slabs.  Same products, different f32 summation order; ignored when
     // k_group is not a multiple of the kernel's K slab.
     int32_t k_group;
+    // B_il != NULL (precision 1 only, optional): the SAME weights as B / B_lo with the two planes interleaved per 32-element K
+    // group — row n is [hi k 0..31 | lo k 0..31 | hi k 32..63 | lo k 32..63 | ...], 2 * ldb elements per row — so that a K slab of a
+    // row is one full 128-byte line instead of one 64-byte segment in each plane (half the L2 requests).  Kernels that do not
+    // take this layout read B / B_lo as before; both must be given.
+    const void* B_il;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

@@ -622,15 +622,21 @@ bool ring_cfg_ok(int cfg, const paa_gemm_desc& d);
 static int g_ring_mode = 0;
 // A/B switches of the selection, read from the environment at the first product and again by every paa_gemm_config call
 // (tools/step_ab.py sets the variables, then calls it): PAA_NO_SQ=1 no 256-column rings, PAA_NO_R2=1 their two-stage form
-// instead of the separate operand rings, PAA_K_GROUP=0 plain K order in the strided convs (gemm_env_kgroup, used by model.hip).
-struct GemmEnv { bool init = false, no_sq = false, no_r2 = false, kgroup = true; };
+// instead of the separate operand rings, PAA_K_GROUP=0 plain K order in the strided convs (gemm_env_kgroup, used by model.hip),
+// PAA_NO_BIL=1 planar weight planes even where the interleaved copy (B_il) is given.
+struct GemmEnv { bool init = false, no_sq = false, no_r2 = false, kgroup = true, no_bil = false; };
 static GemmEnv g_env;
 static void gemm_env_refresh() {
     auto on = [](const char* name, char v) { const char* e = getenv(name); return e && e[0] == v; };
     g_env.no_sq = on("PAA_NO_SQ", '1');
     g_env.no_r2 = on("PAA_NO_R2", '1');
     g_env.kgroup = !on("PAA_K_GROUP", '0');
+    g_env.no_bil = on("PAA_NO_BIL", '1');
     g_env.init = true;
+}
+bool gemm_env_no_bil() {
+    if (!g_env.init) gemm_env_refresh();
+    return g_env.no_bil;
 }
 bool gemm_env_kgroup() {
     if (!g_env.init) gemm_env_refresh();

@@ -24,6 +24,9 @@
 
 namespace paa {
 
+// PAA_NO_BIL=1 (A/B measurements, cached by gemm.hip's environment refresh): planar weights even where B_il is given
+bool gemm_env_no_bil();
+
 namespace {
 
 // 0 (diagnostic builds): every step reads its first fragments at its top instead of under the previous step's last MFMA group
@@ -35,7 +38,9 @@ typedef __attribute__((address_space(3))) void* las_ptr2;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt2() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int BK, int PREC, int WR, int WC>
+// BIL (split mode): the B operand comes from paa_gemm_desc.B_il — hi and lo planes interleaved per 32-element K group — so a K slab
+// of a weight row is ONE 128-byte line; its slot has 128-byte rows (chunks 0-3 hi, 4-7 lo) with the XOR swizzle of the bf16 kernels.
+template <int BM, int BN, int BK, int PREC, int WR, int WC, bool BIL = false>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int NW = WR * WC;
     constexpr int NPL = PREC ? 2 : 1;
@@ -44,15 +49,17 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int RPI = 1024 / RB;             // rows per DMA wave-instruction
     constexpr int RBR = 256 / RB;              // rows per 256-byte bank row
     constexpr int NSTA = 3, NSTB = 2;
-    constexpr int ASZ = NPL * BM * RB, BSZ = NPL * BN * RB;        // one slot of each ring: hi rows [| lo rows]
-    constexpr int GA = NPL * BM / RPI / NW, GB = NPL * BN / RPI / NW;   // DMA wave-instructions per wave per slab
+    static_assert(!BIL || (PREC == 1 && BK == 32), "interleaved planes: split mode, one 32-element K group per slab");
+    constexpr int RBB = BIL ? 128 : RB, CPRB = RBB / 16, RPIB = 1024 / RBB, RBRB = 256 / RBB;      // the B slot's row geometry
+    constexpr int ASZ = NPL * BM * RB, BSZ = NPL * BN * RB;        // one slot of each ring: hi rows [| lo rows]  (BIL: BN rows of 128 bytes)
+    constexpr int GA = NPL * BM / RPI / NW, GB = BSZ / 1024 / NW;   // DMA wave-instructions per wave per slab
     constexpr int MI = BM / WR / 32, NJ = BN / WC / 32, KS = BK / 16;
     // split mode only: the last MFMA group of a K slab runs AFTER the certifying barrier, over the reads of the next slab's first
     // fragments (+0..4 % per product; in bf16 mode a group is two MFMAs — too short to cover an LDS round trip — and the form
     // measured -3..+1 %)
     constexpr bool DEFER = PAA_R2_DEFER && PREC;
     static_assert(NJ == 2, "vector epilogue: 64 columns per wave");
-    static_assert((NPL * BM) % (RPI * NW) == 0 && (NPL * BN) % (RPI * NW) == 0 && BM % RPI == 0 && BN % RPI == 0, "a DMA wave-instruction must not straddle planes");
+    static_assert((NPL * BM) % (RPI * NW) == 0 && (NPL * BN) % (RPI * NW) == 0 && BM % RPI == 0 && BN % RPI == 0 && BSZ % (1024 * NW) == 0, "a DMA wave-instruction must not straddle planes");
     static_assert(NSTA * ASZ + NSTB * BSZ <= 160 * 1024 && GA + GB < 32, "rings do not fit");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTA * ASZ + NSTB * BSZ];
     unsigned char* const smA = smem;
@@ -120,12 +127,16 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         const int64_t boff = c.z1 * d.b_s1 + c.z2 * d.b_s2;
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
-            const int r = (i * NW + wave) * RPI + lane / CPR;
-            const int pl = r / BN, p = r - pl * BN;
-            const int ch = (lane % CPR) ^ ((p / RBR) & (CPR - 1));
-            const unsigned short* B = reinterpret_cast<const unsigned short*>(pl ? d.B_lo : (const void*)d.B) + boff;
+            const int r = (i * NW + wave) * RPIB + lane / CPRB;
+            const int pl = BIL ? 0 : r / BN, p = r - pl * BN;
+            const int ch = (lane % CPRB) ^ ((p / RBRB) & (CPRB - 1));
             const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);      // row permutation of the vector epilogue
-            srcB[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
+            if constexpr (BIL) {
+                srcB[i] = reinterpret_cast<const unsigned short*>(d.B_il) + 2 * boff + (int64_t)min(c.n0 + nl, d.N - 1) * (2 * d.ldb) + ch * 8;
+            } else {
+                const unsigned short* B = reinterpret_cast<const unsigned short*>(pl ? d.B_lo : (const void*)d.B) + boff;
+                srcB[i] = B + (int64_t)min(c.n0 + nl, d.N - 1) * d.ldb + ch * 8;
+            }
         }
     };
     auto issueA = [&]() {                      // -> true if a slab was requested
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         unsigned char* st = smB + cb.slot * BSZ;
 #pragma unroll
         for (int i = 0; i < GB; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcB[i] + (int64_t)cb.slab * BK), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcB[i] + (int64_t)cb.slab * (BIL ? 2 * BK : BK)), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
         if (advance(cb, NSTB) && cb.t < total) set_srcB(cb.t);
     };
     set_srcA(ca.t);
@@ -160,8 +171,16 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     int offk[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
-    const int arow = (wr * (BM / WR) + lr) * RB, brow = (wc * (BN / WC) + lr) * RB;
+    const int arow = (wr * (BM / WR) + lr) * RB, brow = (wc * (BN / WC) + lr) * RBB;
     constexpr int ALO = BM * RB, BLO = BN * RB;     // hi -> lo plane distance inside a slot
+    // B fragment offsets of k slice ks: hi / lo plane (BIL: chunks 2 ks + lh and 4 + 2 ks + lh of the 128-byte row)
+    const int swb = (lr / RBRB) & (CPRB - 1);
+    int offbh[KS], offbl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        offbh[ks] = BIL ? (((2 * ks + lh) ^ swb) << 4) : offk[ks];
+        offbl[ks] = BIL ? (((4 + 2 * ks + lh) ^ swb) << 4) : BLO + offk[ks];
+    }
 
     int sa_slot = 0, sb_slot = 0;              // slots the MFMAs consume next
     constexpr int NM = NJ * (PREC ? 3 : 1);
@@ -189,8 +208,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
             if (!(DEFER && have_first)) {          // first fragments of this slab (else: read under the previous slab's last MFMAs)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[0]);
-                    if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 32 * RB + offk[0]);
+                    bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RBB + offbh[0]);
+                    if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RBB + offbl[0]);
                 }
                 ahn = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
                 if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + ALO + offk[0]);
@@ -211,8 +230,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                         if (ni == 0) {
 #pragma unroll
                             for (int j = 0; j < NJ; ++j) {
-                                bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RB + offk[nks < KS ? nks : 0]);
-                                if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + BLO + j * 32 * RB + offk[nks < KS ? nks : 0]);
+                                bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RBB + offbh[nks < KS ? nks : 0]);
+                                if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RBB + offbl[nks < KS ? nks : 0]);
                             }
                         }
                     } else if (DEFER && !last) {
@@ -228,8 +247,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                         const unsigned char* sbn = smB + sb_slot * BSZ + brow;
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            bhn[j] = *reinterpret_cast<const bf16x8*>(sbn + j * 32 * RB + offk[0]);
-                            if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sbn + BLO + j * 32 * RB + offk[0]);
+                            bhn[j] = *reinterpret_cast<const bf16x8*>(sbn + j * 32 * RBB + offbh[0]);
+                            if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sbn + j * 32 * RBB + offbl[0]);
                         }
                         ahn = *reinterpret_cast<const bf16x8*>(san + offk[0]);
                         if (PREC) aln = *reinterpret_cast<const bf16x8*>(san + ALO + offk[0]);
@@ -282,12 +301,19 @@ int ring2_resident_blocks(K kernel, int threads) {
     return cus * per;
 }
 
-template <int BM, int BN, int BK, int PREC, int WR, int WC>
-void launch_ring2(const GemmArgs& g, hipStream_t st) {
-    static const int resident = ring2_resident_blocks(k_gemm_ring2<BM, BN, BK, PREC, WR, WC>, WR * WC * 64);
+template <int BM, int BN, int BK, int PREC, int WR, int WC, bool BIL>
+void launch_ring2_il(const GemmArgs& g, hipStream_t st) {
+    static const int resident = ring2_resident_blocks(k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL>, WR * WC * 64);
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
-    hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
+    hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
+}
+template <int BM, int BN, int BK, int PREC, int WR, int WC>
+void launch_ring2(const GemmArgs& g, hipStream_t st) {
+    if constexpr (PREC == 1) {
+        if (g.d.B_il && g.d.b_s1 == 0 && g.d.b_s2 == 0 && !gemm_env_no_bil()) { launch_ring2_il<BM, BN, BK, PREC, WR, WC, true>(g, st); return; }
+    }
+    launch_ring2_il<BM, BN, BK, PREC, WR, WC, false>(g, st);
 }
 
 }  // namespace

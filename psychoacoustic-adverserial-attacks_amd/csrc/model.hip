@@ -33,9 +33,10 @@ namespace {
 struct CBf {                       // read-only bf16 planes
     const unsigned short* hi = nullptr;
     const unsigned short* lo = nullptr;
-    CBf off(int64_t e) const { return CBf{hi + e, lo ? lo + e : nullptr}; }
+    const unsigned short* il = nullptr;      // weights, fp32-parity mode: the two planes interleaved per 32-element K group (gemm.h, B_il)
+    CBf off(int64_t e) const { return CBf{hi + e, lo ? lo + e : nullptr, nullptr}; }
 };
-static inline CBf ro(const Bf& b) { return CBf{b.hi, b.lo}; }
+static inline CBf ro(const Bf& b) { return CBf{b.hi, b.lo, nullptr}; }
 static inline Bf boff(const Bf& b, int64_t e) { return Bf{b.hi + e, b.lo ? b.lo + e : nullptr}; }
 static const Bf NOBF{nullptr, nullptr};
 
@@ -147,7 +148,9 @@ static const float* find(paa_model* m, const std::string& n, int64_t numel, paa_
 // bf16 weight planes: "<name>" (hi) and, in fp32-parity mode, "<name>.lo"
 #define NEEDB(dst, name, numel) do { const float* _h; const float* _l = nullptr; NEED(_h, name, numel); \
     if (m->prec) NEED(_l, std::string(name) + ".lo", numel); \
-    dst = CBf{reinterpret_cast<const unsigned short*>(_h), reinterpret_cast<const unsigned short*>(_l)}; } while (0)
+    dst = CBf{reinterpret_cast<const unsigned short*>(_h), reinterpret_cast<const unsigned short*>(_l), nullptr}; \
+    if (m->prec) { auto _it = m->tensors.find(std::string(name) + ".il"); \
+                   if (_it != m->tensors.end() && _it->second.second == 2 * (int64_t)(numel)) dst.il = reinterpret_cast<const unsigned short*>(_it->second.first); } } while (0)
 
 extern "C" void paa_model_destroy(paa_model* m) {
     if (!m) return;
@@ -338,7 +341,7 @@ static paa_gemm_desc gdb(const paa_model* m, CBf A, CBf W, float* C, Bf Cb, int 
                          int64_t ldc) {
     paa_gemm_desc d{};
     d.operand_bf16 = 1;
-    d.A = reinterpret_cast<const float*>(A.hi); d.A_lo = A.lo; d.B = reinterpret_cast<const float*>(W.hi); d.B_lo = W.lo;
+    d.A = reinterpret_cast<const float*>(A.hi); d.A_lo = A.lo; d.B = reinterpret_cast<const float*>(W.hi); d.B_lo = W.lo; d.B_il = W.il;
     d.C = C; d.Cb = Cb.hi; d.Cb_lo = Cb.lo;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
     d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;

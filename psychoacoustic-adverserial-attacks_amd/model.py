@@ -100,6 +100,12 @@ def bf16_bits(x: np.ndarray) -> np.ndarray:
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
+def interleave_planes(hi: np.ndarray, lo: np.ndarray) -> np.ndarray:
+    """[N][K] hi / lo planes -> [N][2K] with the planes interleaved per 32-element K group (paa_gemm_desc.B_il)."""
+    n, k = hi.shape
+    return np.ascontiguousarray(np.stack([hi.reshape(n, k // 32, 32), lo.reshape(n, k // 32, 32)], axis=2).reshape(n, 2 * k))
+
+
 def bf16_to_f32(b: np.ndarray) -> np.ndarray:
     return (b.astype(np.uint32) << 16).view(np.float32)
 
@@ -159,6 +165,8 @@ class PaaModel:
                 planes[k] = hi
                 if dtype == "fp32":
                     planes[k + ".lo"] = lo
+                    if hi.ndim == 2 and hi.shape[1] % 32 == 0:
+                        planes[k + ".il"] = interleave_planes(hi, lo)
             else:
                 planes[k] = v
         # one device byte buffer for all packed weights, 256-byte aligned slices

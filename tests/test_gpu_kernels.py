@@ -251,6 +251,41 @@ def test_gemm_k_group_order(prec, cfg):
         L.paa_gemm_config(0)
 
 
+@pytest.mark.parametrize("cfg", [20, 22])
+def test_gemm_interleaved_weight_planes(cfg):
+    """paa_gemm_desc.B_il: the weights' hi / lo planes interleaved per 32-element K group (one 128-byte line per K slab of a row).
+    Same products in the same order as the planar form, so the results must be bit-identical to it (and it is checked against
+    numpy by test_gemm_ring_configurations)."""
+    from paa_amd.model import interleave_planes, split_bf16
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    M, N, K = 2200, 512, 384
+    A, B = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(N, K)).astype(np.float32)
+    (ah, al), (bh, bl) = split_bf16(A), split_bf16(B)
+    t = {k: torch.from_numpy(v.view(np.int16)).cuda() for k, v in dict(ah=ah, al=al, bh=bh, bl=bl, bil=interleave_planes(bh, bl)).items()}
+    bias = torch.from_numpy(rng.normal(size=N).astype(np.float32)).cuda()
+    outs = []
+    try:
+        L.paa_gemm_config(cfg)
+        for il in (False, True):
+            d = _lib.PaaGemmDesc()
+            d.A, d.A_lo, d.B, d.B_lo = t["ah"].data_ptr(), t["al"].data_ptr(), t["bh"].data_ptr(), t["bl"].data_ptr()
+            d.B_il = t["bil"].data_ptr() if il else None
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, K, K, N
+            d.a_kcontig = d.b_kcontig = d.batch = d.batch2 = d.operand_bf16 = d.precision = 1
+            d.alpha, d.act, d.aux_gate, d.bias = 0.5, 1, 1, bias.data_ptr()
+            pre = torch.zeros(M * N, device="cuda"); cb = torch.zeros(M * N, dtype=torch.int16, device="cuda"); cbl = torch.zeros_like(cb)
+            d.C_pre, d.Cb, d.Cb_lo = pre.data_ptr(), cb.data_ptr(), cbl.data_ptr()
+            _lib.check(L.paa_gemm(C.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            outs.append((pre.clone(), cb.clone(), cbl.clone()))
+    finally:
+        L.paa_gemm_config(0)
+    assert float(outs[0][0].abs().max()) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_layernorm_fwd_bwd():
     torch.manual_seed(0)
     for rows, cols in ((37, 512), (130, 768), (9, 64), (5, 32)):

@@ -17,8 +17,9 @@ from paa_amd.training_utils.pgd import PgdStepper
 
 
 # auto = automatic selection, reg = register-staged kernels only; nosq = without the 256-column rings; nor2 = two-stage 256-column
-# rings instead of the separate operand rings (gemm_ring2.hip); nokg = plain K order in the convs
-VARIANTS = ("auto", "auto nor2", "auto nosq", "reg")
+# rings instead of the separate operand rings (gemm_ring2.hip); nobil = planar weight planes instead of the interleaved copy; nokg =
+# plain K order in the convs
+VARIANTS = ("auto", "auto nobil", "auto nor2", "reg")
 
 
 def main(steps=15, rounds=3):
@@ -39,6 +40,7 @@ def main(steps=15, rounds=3):
                 os.environ["PAA_K_GROUP"] = "0" if "nokg" in cfg else "1"
                 os.environ["PAA_NO_SQ"] = "1" if "nosq" in cfg else "0"
                 os.environ["PAA_NO_R2"] = "1" if "nor2" in cfg else "0"
+                os.environ["PAA_NO_BIL"] = "1" if "nobil" in cfg else "0"
                 lib.paa_gemm_config(1 if "reg" in cfg else 0)
                 for _ in range(2):
                     st.step(p, clean, labels, want_logits=False)
