@@ -128,7 +128,10 @@ typedef struct {
 } paa_tensor;
 
 /* precision: 0 = bf16 MFMA operands / f32 accumulate; 1 = split-bf16 (hi+lo, 3 MFMA passes),
- * fp32-parity mode.  Activations are stored in f32 in both modes. */
+ * fp32-parity mode.  Activations are stored in f32 in both modes.
+ * GEMM weights arrive as bf16 bit patterns: "<name>" (hi plane) and, for precision 1, "<name>.lo" (lo plane, bf16(w - hi));
+ * optionally "<name>.il" (precision 1, 2 * numel elements): the same two planes interleaved per 32-element K group of each
+ * row, [32 hi | 32 lo | 32 hi | ...] — used by the large products where present (csrc/gemm.h, B_il), never required. */
 typedef struct paa_model paa_model;
 paa_status paa_model_create(paa_model** out, const paa_arch* arch, const paa_tensor* tensors, int n_tensors,
                             int max_batch, int length, int precision);
