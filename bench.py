@@ -63,7 +63,10 @@ def parse():
     ap.add_argument("--no_prof", action="store_true", help="skip the per-launch GEMM event timing")
     ap.add_argument("--prof_steps", type=int, default=1,
                     help="number of timed steps (the last ones) whose GEMM launches carry HIP events; 0 = every timed step")
-    ap.add_argument("--graph", action="store_true", help="replay the step from captured hipGraphs (implies --no_prof)")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every step eagerly; default: the step is replayed from captured hipGraphs (BASELINE.md section 3 protocol; "
+                         "same kernels, bit-identical results, same time — profiles/r3_graph_vs_eager_ab.txt), except the last "
+                         "--prof_steps timed steps, which are launched eagerly so that HIP events can bracket every GEMM")
     ap.add_argument("--pmc_json", default=None, help="tools/pmc_summary.py output of THIS commit: fills roofline.traffic (else null)")
     ap.add_argument("--no_fft_bench", action="store_true", help="skip the FFT / projection path timing (roofline_fft block)")
     return ap.parse_args()
@@ -229,15 +232,19 @@ def main():
         book = {"loss": [], "wer": [], "wer_global": []}
         no_prof = ar.no_prof
         graphs = None
-        if ar.graph:
-            no_prof = True
+        if not ar.eager:
             graphs = [stepper.capture(p, cleans[j], labels[j], logits_out=logits_buf[j % 2]) for j in range(NB)]
             p.copy_(p0)                              # capture ran the step for real: restore the starting point
+        # the last n_prof timed steps run eagerly (events around every GEMM cannot be recorded inside a replay)
+        n_prof = 0 if (no_prof or rank != 0) else (ar.steps if ar.prof_steps <= 0 else min(ar.prof_steps, ar.steps))
+        prof_from = ar.warmup + ar.steps - n_prof
+        replayed = [0]
 
         def launch(i):
             k = i % 2
-            if graphs is not None:
+            if graphs is not None and not (n_prof and i >= prof_from):
                 graphs[i % NB][0].replay()
+                replayed[0] += 1
                 r = graphs[i % NB][1]
             else:
                 r = stepper.step(p, cleans[i % NB], labels[i % NB], want_logits=True, logits_out=logits_buf[k])
@@ -275,8 +282,6 @@ def main():
         # event recorded on a stream switches its HIP queue to profiled dispatch for the rest of the process, which slows
         # every later launch (~4 %); recording at the end keeps the steps before it unperturbed while the sample is
         # still taken live inside the timed region.  --prof_steps 0: every timed step.
-        n_prof = ar.steps if ar.prof_steps <= 0 else min(ar.prof_steps, ar.steps)
-        prof_from = ar.warmup + ar.steps - n_prof
         if prof_on:
             _lib.check(lib.paa_prof_enable(4096 * n_prof))
             _lib.check(lib.paa_prof_pause(1))
@@ -316,7 +321,7 @@ def main():
                             "avg_launch_us": round(ms * 1e3 / n, 2), "algorithmic_bytes_per_launch": int(by / n),
                             "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1),
                             "mfma_passes_per_product": passes, "mfma_issue_frac": round(passes * achieved / MFMA_PEAK, 4),
-                            "sampled_steps": n_prof, "share_of_step": round(ms * 1e-3 / (dt * n_prof / ar.steps), 4),
+                            "sampled_steps": n_prof, "share_of_step": round(ms * 1e-3 / (dt * max(n_prof, 1) / ar.steps), 4),
                             "all_gemm_variants": [{"kernel": VARIANTS[r[0]], "launches": int(r[1]), "ms": round(r[2], 3),
                                                    "tflops": round(r[3] / (r[2] * 1e-3) / 1e12, 2),
                                                    "algorithmic_MB_per_launch": round(r[4] / r[1] / 1e6, 1)} for r in rows]}
@@ -324,7 +329,7 @@ def main():
         res = {"value": round(world * ar.steps / dt, 4), "ms_per_step": round(1e3 * dt / ar.steps, 3), "timed_region_s": round(dt, 3),
                "dtype": DTYPE_NAME[dtype], "model_tflops_achieved_per_gpu": round(fl_step / (dt / ar.steps) / 1e12, 2),
                "step_frac_of_mfma_peak": round(passes * fl_step / (dt / ar.steps) / 1e12 / MFMA_PEAK, 4),
-               "hip_graph": bool(graphs), "last_loss": book["loss"][-1], "last_wer": book["wer"][-1], "roofline": roofline}
+               "hip_graph": bool(graphs), "hip_graph_replayed_steps": replayed[0] - (ar.warmup if graphs else 0), "last_loss": book["loss"][-1], "last_wer": book["wer"][-1], "roofline": roofline}
         if book["wer_global"]:
             res["last_wer_all_ranks"] = book["wer_global"][-1]
         # the gradient of ONE more step from the common starting point, for the cross-mode comparison below
@@ -358,7 +363,7 @@ def main():
                        "model_tflop_per_step_per_gpu": round(fl_step / 1e12, 3),
                        "model_tflops_achieved_per_gpu": head["model_tflops_achieved_per_gpu"],
                        "timed_region_s": head["timed_region_s"],
-                       "hip_graph": head["hip_graph"], "last_loss": head["last_loss"], "last_wer": head["last_wer"]},
+                       "hip_graph": head["hip_graph"], "hip_graph_replayed_steps": head["hip_graph_replayed_steps"], "last_loss": head["last_loss"], "last_wer": head["last_wer"]},
             "roofline": head["roofline"],
         }
         if "last_wer_all_ranks" in head:
@@ -385,7 +390,7 @@ def main():
             ts = cpu_baseline(a, args0, L, cb, ar.label_tokens, 5, ar.cpu_steps, weight_grads=False)
             t_cpu = sum(ts) / len(ts)
             res["cpu_baseline"] = {"value": round((cb / B) / t_cpu, 5), "unit": "steps/s (32-clip step equivalents)",
-                                   "cores": nthreads, "kind": "port",
+                                   "cores": nthreads, "kind": f"port, extrapolated from {cb} of {B} clips",
                                    "sample": f"oracle PGD step (torch CPU fp32, same arch/labels/length, input gradient only) on {cb} of the "
                                              f"{B} clips: 1 warm-up + {len(ts)} timed steps, mean {t_cpu:.2f} s "
                                              f"(each: {', '.join(f'{t:.2f}' for t in ts)}), scaled by {cb}/{B}"}

@@ -44,6 +44,8 @@ typedef struct {
 } paa_params;
 
 const char* paa_last_error(void);
+/* 300 = this header; 301 = the same ABI built with -DPAA_EXPERIMENTS (diagnostic kernels and environment switches compiled in,
+ * tools/ only).  Bindings refuse other values. */
 int paa_version(void);
 /* sizeof(paa_params), sizeof(paa_arch), sizeof(paa_tensor), sizeof(paa_gemm_desc): layout check for bindings */
 void paa_abi_sizes(int32_t* out4);
@@ -87,11 +89,18 @@ paa_status paa_spectrum_project(paa_proj* h, const paa_params* prm, const float*
 paa_status paa_fm_weighted_norm(paa_proj* h, const float* d_S, int B, int T, float* d_out, void* stream);
 
 /* Data-parallel form: project_snr / project_tv use whole-batch statistics of the clean
- * audio, so ranks all-reduce [sum clean^2, TV(clean)] (paa_batch_stats on each shard) and pass the
- * global values plus the global element count here instead of the clean batch itself. */
-paa_status paa_batch_stats(paa_proj* h, const float* d_clean, int B, int L, float* d_out2, void* stream);
+ * audio (projections.py:11-35, 56-66), so every rank reduces its shard with paa_batch_stats —
+ * d_out2 = [sum clean^2, TV(clean)], d_clip_count[0] = (float)B (nullable) — the caller all-reduces
+ * these three numbers with the gradient, and paa_project_ext projects from the GLOBAL values:
+ * d_clean_stats = device [sum clean^2, TV(clean)] over all ranks; the SNR target norm's clean.numel()
+ * (projections.py:27) is d_clip_count[0] * L when d_clip_count (device, the all-reduced clip count — a
+ * small integer, exact in f32) is given, else the host value clean_numel.  Nothing here depends on the
+ * local batch size being equal across ranks or steps. */
+paa_status paa_batch_stats(paa_proj* h, const float* d_clean, int B, int L, float* d_out2, float* d_clip_count,
+                           void* stream);
 paa_status paa_project_ext(paa_proj* h, const paa_params* prm, float* d_p, int rows_p,
-                           const float* d_clean_stats /* device [2] */, double clean_numel, int L, void* stream);
+                           const float* d_clean_stats /* device [2] */, const float* d_clip_count /* device [1] or NULL */,
+                           double clean_numel /* used when d_clip_count is NULL */, int L, void* stream);
 
 /* core/fourier_transforms.py:4-29 compute_stft: (B, L) -> d_out (B, T, F) complex64 interleaved,
  * T = 1 + L / hop; the (B, F, T) tensor the reference returns is the transpose-view of this. */
@@ -146,7 +155,8 @@ int paa_model_frames(const paa_model* m);     /* T_e for the configured length *
  *   d_stats  (8) out: [0] loss (sum over the batch, HF ctc_loss_reduction='sum').  Slots [1..7] are NOT written by
  *            this call: they belong to the caller's data-parallel bookkeeping (paa_amd/training_utils/pgd.py packs
  *            [1] sum clean^2 and [2] TV(clean) from paa_batch_stats, [3] WER word errors, [4] WER reference words,
- *            [5] local clean element count behind the gradient so that ONE all-reduce carries everything).
+ *            [5] the local clip count B (paa_batch_stats), behind the gradient, so that ONE all-reduce carries everything
+ *            and the global clean.numel() = L * sum_r B_r needs no collective of its own).
  */
 paa_status paa_model_fwd_bwd(paa_model* m, const float* d_clean, const float* d_p, const int32_t* d_labels,
                              int B, int S_max, int direction, float* d_grad, float* d_logits, float* d_stats,
@@ -172,10 +182,15 @@ int paa_model_layout(const paa_model* m, int i);  /* padded rows of conv layer i
 struct paa_gemm_desc;
 paa_status paa_gemm(const struct paa_gemm_desc* d, void* stream);
 /* Test / measurement aid: kernel selection of paa_gemm for the large regular products.  0 = automatic (default),
- * 1 = register-staged kernels only, 2..8 = force one LDS-DMA ring configuration wherever its shape constraints hold
- * (csrc/gemm_ring.hip).  Results are bit-identical across configurations 0..8 (same K order); tests assert that.
- * (9 / 10 exist only under PAA_MF16_PROBE=1: MFMA-shape timing probes whose results are wrong by construction.) */
+ * 1 = register-staged kernels only, else force ONE LDS-DMA ring configuration wherever its shape constraints hold: 7 / 8 =
+ * 192 x 128 split / bf16 (csrc/gemm_ring.hip), 20 / 21 = 256 x 256 split / bf16, 22 / 23 = 192 x 256 split / bf16
+ * (csrc/gemm_ring2.hip).  Results are bit-identical across all of them (same K order); tests assert that.  Any other value
+ * selects a configuration only a -DPAA_EXPERIMENTS build holds (measured and rejected variants, timing probes); the shipped
+ * library falls back to the register-staged kernels for it. */
 void paa_gemm_config(int ring_mode);
+/* Test aid.  option 0: value != 0 makes the GroupNorm backward of conv0 take its statistics-pass + GEMM-pass path (the fallback of
+ * the shapes the fused single-pass kernel does not cover) on every shape, so that tests can compare the two on the same operands. */
+paa_status paa_test_option(int option, int value);
 /* Measurement aid (bench.py roofline leg): HIP-event timing of every GEMM launch on its own stream.
  * paa_prof_enable(n>0) starts recording up to n launches (0 stops); paa_prof_read fills out[64][4] =
  * {launches, total ms, total algorithmic FLOP (2*M*N*K*batch), total algorithmic HBM bytes (every operand and result

@@ -8,6 +8,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpaa_hip.so")
 
+ABI_VERSIONS = (300, 301)      # include/paa_hip.h paa_version: 301 = the same ABI built with -DPAA_EXPERIMENTS
+
 PAA_OK, PAA_ERR_BAD_NORM, PAA_ERR_NEED_CLEAN, PAA_ERR_SIZE, PAA_ERR_HIP, PAA_ERR_ARG, PAA_ERR_MISSING = range(7)
 
 NORM_IDS = {"l2": 0, "linf": 1, "snr": 2, "tv": 3, "fletcher_munson": 4, "min_max_freqs": 5, "max_phon": 6}
@@ -64,9 +66,9 @@ _SIGS = {
                                  C.c_void_p]),
     "paa_spectrum_project": (C.c_int, [C.c_void_p, C.POINTER(PaaParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "paa_fm_weighted_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "paa_project_ext": (C.c_int, [C.c_void_p, C.POINTER(PaaParams), C.c_void_p, C.c_int, C.c_void_p, C.c_double,
+    "paa_project_ext": (C.c_int, [C.c_void_p, C.POINTER(PaaParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                   C.c_int, C.c_void_p]),
-    "paa_batch_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "paa_batch_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "paa_stft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "paa_istft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "paa_sign_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
@@ -86,6 +88,7 @@ _SIGS = {
     "paa_model_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "paa_gemm": (C.c_int, [C.POINTER(PaaGemmDesc), C.c_void_p]),
     "paa_gemm_config": (None, [C.c_int]),
+    "paa_test_option": (C.c_int, [C.c_int, C.c_int]),
     "paa_prof_enable": (C.c_int, [C.c_int]),
     "paa_prof_read": (C.c_int, [C.c_void_p]),
     "paa_prof_pause": (C.c_int, [C.c_int]),
@@ -112,6 +115,18 @@ class PaaError(RuntimeError):
         self.msg = msg
 
 
+def _check_current():
+    """A library built from other sources than the ones next to it is refused (content hash, build_ext.source_key): a stale
+    kernel would pass the ABI-size check and silently compute with old code."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("paa_build_ext", os.path.join(HERE, "build_ext.py"))
+    be = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(be)
+    if os.environ.get("PAA_EXTRA_HIPCC_FLAGS") is None and not be.is_current():
+        raise RuntimeError(f"{LIB_PATH} was not built from the sources in {be.CSRC} (content hash mismatch): run "
+                           "`python __graft_entry__.py build`")
+
+
 def lib():
     """Load libpaa_hip.so (built in-tree by paa_amd.build_ext / __graft_entry__.build)."""
     global _lib
@@ -119,11 +134,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "
                                "There is no CPU fallback for the product path.")
+        _check_current()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        ver = L.paa_version()
+        if ver not in ABI_VERSIONS:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {ver}, this binding needs one of {ABI_VERSIONS}: rebuild "
+                               "(`python __graft_entry__.py build`)")
         sizes = (C.c_int32 * 4)()
         L.paa_abi_sizes(sizes)
         mine = [C.sizeof(PaaParams), C.sizeof(PaaArch), C.sizeof(PaaTensor), C.sizeof(PaaGemmDesc)]

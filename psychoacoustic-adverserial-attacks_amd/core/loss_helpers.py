@@ -117,15 +117,20 @@ def wer_counts(pred_texts, ref_texts):
     return errs, sum(len(r.split()) for r in ref_texts)
 
 
-def compute_wer(logits, target_texts, processor, wer_metric):
-    """loss_helpers.py:25-32."""
+def wer_texts(logits, target_texts, processor):
+    """The two string lists loss_helpers.py:26-30 hands to the WER metric: greedy CTC decode of ``logits`` and the cleaned
+    references, both lower-cased."""
     pred_ids = argmax_ids(logits)
     if processor is not None:
         pred_texts = processor.batch_decode(pred_ids.long().cpu(), skip_special_tokens=True)
     else:
         pred_texts = greedy_decode_ids(pred_ids.tolist())
-    pred_texts = [p.strip().lower() for p in pred_texts]
-    ref_texts = [t.lower() for t in clean_transcripts(target_texts)]
+    return [p.strip().lower() for p in pred_texts], [t.lower() for t in clean_transcripts(target_texts)]
+
+
+def compute_wer(logits, target_texts, processor, wer_metric):
+    """loss_helpers.py:25-32."""
+    pred_texts, ref_texts = wer_texts(logits, target_texts, processor)
     if wer_metric is not None:
         return wer_metric.compute(predictions=pred_texts, references=ref_texts)
     e, w = wer_counts(pred_texts, ref_texts)

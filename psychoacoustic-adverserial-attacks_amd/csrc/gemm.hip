@@ -592,19 +592,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
     epilogue<2, MI>(d, acc, m0 + wave * (32 * MI) + 4 * lh, lr, z1, z2);
 }
 
-// resident workgroups of a kernel on this device (CUs x occupancy), cached per kernel
-template <typename K>
-static int resident_blocks(K kernel, int threads) {
-    int dev = 0, cus = 0, per = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) return 0;
-    return cus * per;
-}
-
 template <int BM, int BN, int PREC, int WM, bool VEC, bool SEG, bool SWZ = false>
 static void launch_bf(const GemmArgs& g, hipStream_t st) {
-    static const int resident = resident_blocks(k_gemm_bf<BM, BN, PREC, WM, VEC, SEG, SWZ>, WM * 128);
+    static const int per_cu = blocks_per_cu(k_gemm_bf<BM, BN, PREC, WM, VEC, SEG, SWZ>, WM * 128);
+    const int resident = per_cu * device_cus();
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
     hipLaunchKernelGGL((k_gemm_bf<BM, BN, PREC, WM, VEC, SEG, SWZ>), dim3(blocks), dim3(WM * 128), 0, st, g);
@@ -620,18 +611,20 @@ bool ring_cfg_ok(int cfg, const paa_gemm_desc& d);
 // Ring-kernel selection (paa_gemm_config): 0 = automatic, 1 = never (the register-staged kernels of round 1),
 // 2.. = force one ring configuration where its shape constraints hold (kernel A/B runs in tools/gemm_bench.py).
 static int g_ring_mode = 0;
-// A/B switches of the selection, read from the environment at the first product and again by every paa_gemm_config call
-// (tools/step_ab.py sets the variables, then calls it): PAA_NO_SQ=1 no 256-column rings, PAA_NO_R2=1 their two-stage form
-// instead of the separate operand rings, PAA_K_GROUP=0 plain K order in the strided convs (gemm_env_kgroup, used by model.hip),
-// PAA_NO_BIL=1 planar weight planes even where the interleaved copy (B_il) is given.
+// A/B switches of the selection exist only in -DPAA_EXPERIMENTS builds (tools/step_ab.py), read from the environment at the first
+// product and again by every paa_gemm_config call: PAA_NO_SQ=1 no 256-column rings, PAA_NO_R2=1 their two-stage form instead of
+// the separate operand rings, PAA_K_GROUP=0 plain K order in the strided convs (gemm_env_kgroup, used by model.hip), PAA_NO_BIL=1
+// planar weight planes even where the interleaved copy (B_il) is given.  The shipped library reads no environment variable here.
 struct GemmEnv { bool init = false, no_sq = false, no_r2 = false, kgroup = true, no_bil = false; };
 static GemmEnv g_env;
 static void gemm_env_refresh() {
+#ifdef PAA_EXPERIMENTS
     auto on = [](const char* name, char v) { const char* e = getenv(name); return e && e[0] == v; };
     g_env.no_sq = on("PAA_NO_SQ", '1');
     g_env.no_r2 = on("PAA_NO_R2", '1');
     g_env.kgroup = !on("PAA_K_GROUP", '0');
     g_env.no_bil = on("PAA_NO_BIL", '1');
+#endif
     g_env.init = true;
 }
 bool gemm_env_no_bil() {
@@ -699,7 +692,8 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     // persistent grid (M = 16000, N = 768: 378 tiles of 256 rows leave a quarter of the 512 slots idle, 504 of 192 fill them)
     bool bm192 = false;
     if (tall && !d.precision) {
-        static const int slots = std::max(1, resident_blocks(k_gemm_bf<256, 128, 0, 2, true, false>, 256));
+        static const int per_cu = std::max(1, blocks_per_cu(k_gemm_bf<256, 128, 0, 2, true, false>, 256));
+        const int slots = per_cu * device_cus();
         const int64_t tn = cdiv(d.N, 128);
         const int64_t t256 = (int64_t)cdiv(d.M, 256) * tn * d.batch, t192 = (int64_t)cdiv(d.M, 192) * tn * d.batch;
         const double c256 = (double)((t256 + slots - 1) / slots) * 256.0, c192 = (double)((t192 + slots - 1) / slots) * 192.0 * 1.05;
@@ -717,14 +711,14 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         const bool no_sq = g_env.no_sq;                  // A/B measurements: automatic selection without the 256-column rings
         if (g_ring_mode >= 2) ring = g_ring_mode;
         else if (d.precision) {
-            const int64_t slots = 256;
+            const int64_t slots = device_cus();              // one 8-wave workgroup per CU
             const int64_t r256 = (t128 + slots - 1) / slots;                       // rounds of 256 x 128 tiles, one workgroup per CU
             const int64_t t192 = (int64_t)cdiv(d.M, 192) * cdiv(d.N, 128) * d.batch;
             const int64_t r192 = (t192 + 2 * slots - 1) / (2 * slots);             // rounds of 192 x 128 tiles, two per CU
             const int64_t rsq = (t256 + slots - 1) / slots;                        // rounds of 256 x 256 tiles, one per CU
             // cost = rounds x per-CU work of a round (in 128-column units), divided by the per-flop efficiency each
             // kernel measured against the register-staged 256 x 128 one (tools/gemm_ring_bench.py, profiles/r2_gemm_ab_sq.txt):
-            // the 256 x 256 ring (17: eight waves, 2 x 64 KB) is 8..10 % faster per flop — conv stack, N = 3072 — and
+            // the 256 x 256 ring (20: eight waves, three A + two B slots) is 8..10 % faster per flop — conv stack, N = 3072 — and
             // fetches each A panel for 2 column tiles instead of 4; the 192 x 128 ring (7) wins where its tiles fill the
             // last round (N = 768 / 2304 at M = 16000).
             // (13 = the register-staged 192 x 128 split tile with swizzled, unpadded LDS, two workgroups per CU — whole
@@ -734,32 +728,39 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             ring = 0;
             double best = c256;
             if (c192 < best) { best = c192; ring = 7; }
-            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(17, d) && csq < best) { best = csq; ring = 17; }
-            // 192 x 256 ring (18: eight waves, 2 x 56 KB, one per CU): M = 16000, N = 768 is 252 tiles on 256 CUs; +3..11 % over
+            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(20, d) && csq < best) { best = csq; ring = 20; }
+            // 192 x 256 ring (22: eight waves, one per CU): M = 16000, N = 768 is 252 tiles on 256 CUs; +3..11 % over
             // ring 7 on the N = 768 / 2304 products
             const int64_t r18 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 256) * d.batch + slots - 1) / slots;
             const double c18 = (double)r18 * 384.0 / 1.05;
-            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(18, d) && c18 < best) { best = c18; ring = 18; }
+            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(22, d) && c18 < best) { best = c18; ring = 22; }
         } else if (bm192) {
             ring = 8;             // bf16: wherever 192-row tiles fill the grid better (N = 768 / 2304: +3..10 %)
-            // one 192 x 256 tile per CU (19) instead of two 192 x 128 (8) where it needs no more rounds: +1..3 % (N = 768)
-            const int64_t r8 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 128) * d.batch + 511) / 512, r19 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 256) * d.batch + 255) / 256;
-            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(19, d) && r19 <= r8) ring = 19;
-        } else if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(2, d)) {
-            // bf16, 256 x 256 ring (2): ties the register-staged 256 x 128 kernel on time (within 3 %) where its tiles
+            // one 192 x 256 tile per CU (23) instead of two 192 x 128 (8) where it needs no more rounds: +1..3 % (N = 768)
+            const int64_t cus = device_cus();
+            const int64_t r8 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 128) * d.batch + 2 * cus - 1) / (2 * cus), r19 = ((int64_t)cdiv(d.M, 192) * cdiv(d.N, 256) * d.batch + cus - 1) / cus;
+            if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(23, d) && r19 <= r8) ring = 23;
+        } else if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(21, d)) {
+            // bf16, 256 x 256 ring (21): ties the register-staged 256 x 128 kernel on time (within 3 %) where its tiles
             // fill the grid equally well, and halves the A-panel fetches from the fabric (profiles/r2_kgroup_pmc.txt)
-            static const int slots2 = std::max(1, resident_blocks(k_gemm_bf<256, 128, 0, 2, true, false>, 256));
-            const int64_t r2 = (t128 + slots2 - 1) / slots2, rsq = (t256 + 255) / 256;
-            if (rsq <= r2) ring = 2;      // a round is one 256 x 256 tile or two co-resident 256 x 128 tiles per CU: equal work
+            static const int per_cu2 = std::max(1, blocks_per_cu(k_gemm_bf<256, 128, 0, 2, true, false>, 256));
+            const int64_t cus = device_cus(), slots2 = per_cu2 * cus;
+            const int64_t r2 = (t128 + slots2 - 1) / slots2, rsq = (t256 + cus - 1) / cus;
+            if (rsq <= r2) ring = 21;     // a round is one 256 x 256 tile or two co-resident 256 x 128 tiles per CU: equal work
         }
-        // separate operand rings (gemm_ring2.hip: three A slots, two B slots) for the 256-column tiles: +0..5 % per product over the
-        // two-stage rings; PAA_NO_R2=1 (A/B measurements) keeps the two-stage forms
-        if (g_ring_mode < 2 && (ring == 17 || ring == 2 || ring == 18 || ring == 19)) {
-            const int r2 = ring == 17 ? 20 : ring == 2 ? 21 : ring == 18 ? 22 : 23;
-            if (!g_env.no_r2 && ring_cfg_ok(r2, d)) ring = r2;
+        // 20..23 are the separate-operand-ring kernels (gemm_ring2.hip: three A slots, two B slots): +0..5 % per product over the
+        // two-stage rings 17 / 2 / 18 / 19 of gemm_ring.hip, which only -DPAA_EXPERIMENTS builds hold (PAA_NO_R2=1 selects them)
+#ifdef PAA_EXPERIMENTS
+        if (g_ring_mode < 2 && g_env.no_r2 && ring >= 20) {
+            const int r1 = ring == 20 ? 17 : ring == 21 ? 2 : ring == 22 ? 18 : 19;
+            if (ring_cfg_ok(r1, d)) ring = r1;
         }
+#endif
+#ifdef PAA_EXPERIMENTS
         if (ring == 13) { if (!d.precision) ring = 0; }          // 13: register-staged 192 x 128 split tile, swizzled LDS, two workgroups per CU
-        else if (ring && !ring_cfg_ok(ring, d)) ring = 0;
+        else
+#endif
+        if (ring && !ring_cfg_ok(ring, d)) ring = 0;
     }
     const int ring_bn = ring == 13 ? 128 : ring ? ring_tile_cols(ring) : 0, ring_bm = ring == 13 ? 192 : ring ? ring_tile_rows(ring) : 0;
     g.tiles_m = cdiv(d.M, ring ? ring_bm : tall ? (bm192 ? 192 : 256) : G_BM);
@@ -815,8 +816,11 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     if (ring) {
         // ring variants by tile: 192 x 128 -> 60 / 61 (bf16 / split), 256 x 256 -> 56 / 57, 192 x 256 -> 52 / 53, 256 x 128 -> 48 / 49
         if (prof) g_prof.variant[g_prof.n] = (ring_bm == 192 ? (ring_bn == 128 ? 60 : 52) : (ring_bn == 256 ? 56 : 48)) + (d.precision ? 1 : 0);
+#ifdef PAA_EXPERIMENTS
         if (ring == 13) launch_bf<192, 128, 1, 2, true, false, true>(g, st);
-        else if (ring >= 20) launch_ring2_cfg(ring, g, st);
+        else
+#endif
+        if (ring >= 20) launch_ring2_cfg(ring, g, st);
         else launch_ring_cfg(ring, g, st);
     } else if (d.operand_bf16) {
         const bool seg = d.a_kseg > 0 || (d.K & 63);          // segmented / windowed A or a K tail: general loader

@@ -17,6 +17,29 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
+// ---- persistent-grid sizing (host) ----------------------------------------------------------------
+// Compute units of the CURRENT device, cached per device id (a process may drive several devices, and a partitioned part
+// reports fewer CUs than the 256 of a whole MI355X).
+inline int device_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cache[dev]) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cache[dev] = c;
+    }
+    return cache[dev];
+}
+// Workgroups of `kernel` one CU holds: a property of the code object (registers, LDS), equal on every gfx950 device, so a
+// per-kernel static may cache it; the grid is this times device_cus() of the device in use.
+template <typename K>
+inline int blocks_per_cu(K kernel, int threads) {
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) return 0;
+    return per;
+}
+
 // ---- epilogue shared by both main loops ---------------------------------------------------------
 // Lane (lr, lh) of a wave holds column n = ... + lr and rows (e&3) + 8(e>>2) + 4 lh of each 32 x 32 accumulator.
 // All per-element offsets are 32-bit and relative to per-wave base pointers (tile-local row * ld + column).

@@ -20,6 +20,12 @@ namespace paa {
 // fragment reads apply the same XOR (f = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows: every
 // ds_read_b128 lane group then covers all 64 banks).  B rows are permuted inside each 64-row group exactly as
 // store_bf<PERM> does, for the vector epilogue.  Stage layout: A_hi rows | B_hi rows [| A_lo rows | B_lo rows].
+// Everything diagnostic in this file — the clock stamps, the ablation bits, the MFMA-shape probe and every ring configuration the
+// automatic selection of gemm.hip cannot reach — is compiled only with -DPAA_EXPERIMENTS (tools/*.sh pass it through
+// PAA_EXTRA_HIPCC_FLAGS).  The shipped library holds configurations 7 and 8 (192 x 128, two workgroups per CU) from this file.
+#if (defined(PAA_CLOCK_STAMP) || defined(PAA_ABL)) && !defined(PAA_EXPERIMENTS)
+#error "PAA_CLOCK_STAMP / PAA_ABL are diagnostic builds: add -DPAA_EXPERIMENTS"
+#endif
 #ifdef PAA_CLOCK_STAMP
 // Diagnostic build only (tools/clock_probe.py): shader-clock ticks and 100 MHz real-time ticks around each workgroup's
 // whole tile loop, written to a buffer of their own that nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6).
@@ -308,19 +314,10 @@ __global__ __launch_bounds__(WR * WC * 64, WPS) void k_gemm_ring(GemmArgs g) {
 #endif
 }
 
-// resident workgroups of a kernel on this device (CUs x occupancy)
-template <typename K>
-static int ring_resident_blocks(K kernel, int threads) {
-    int dev = 0, cus = 0, per = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) return 0;
-    return cus * per;
-}
-
 template <int BM, int BN, int BK, int PREC, int NST, int WR, int WC, bool AHEAD, int WPS = 2, bool MF16 = false>
 static void launch_ring(const GemmArgs& g, hipStream_t st) {
-    static const int resident = ring_resident_blocks(k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS, MF16>, WR * WC * 64);
+    static const int per_cu = blocks_per_cu(k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS, MF16>, WR * WC * 64);
+    const int resident = per_cu * device_cus();
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
     hipLaunchKernelGGL((k_gemm_ring<BM, BN, BK, PREC, NST, WR, WC, AHEAD, WPS, MF16>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
@@ -328,23 +325,25 @@ static void launch_ring(const GemmArgs& g, hipStream_t st) {
 
 void launch_ring_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
     switch (cfg) {
+        case 7: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2>(g, st); break;  // split, 192-row tiles, 2 x 40 KB, two workgroups per CU
+        case 8: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2>(g, st); break;  // bf16, 192-row tiles, 2 x 40 KB, two workgroups per CU
+#ifdef PAA_EXPERIMENTS      // measured and not selected; results equal to the shipped kernels except 9 / 10
         case 2: launch_ring<256, 256, 64, 0, 2, 2, 4, false>(g, st); break;     // bf16, 2 stages of 64 KB (the round-1 structure)
         case 3: launch_ring<256, 256, 32, 0, 4, 2, 4, false>(g, st); break;     // bf16, 4 stages of 32 KB, 3 in flight
         case 4: launch_ring<256, 128, 32, 1, 3, 4, 2, false>(g, st); break;     // split, 3 stages of 48 KB, 2 in flight
         case 5: launch_ring<256, 256, 32, 0, 4, 2, 4, true>(g, st); break;      // bf16, 4 stages, certified one ahead
         case 6: launch_ring<256, 128, 32, 1, 3, 4, 2, true>(g, st); break;      // split, 3 stages, certified one ahead
-        case 7: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2>(g, st); break;  // split, 192-row tiles, 2 x 40 KB, two workgroups per CU
-        case 8: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2>(g, st); break;  // bf16, 192-row tiles, 2 x 40 KB, two workgroups per CU
         case 11: launch_ring<192, 128, 16, 1, 4, 2, 2, false, 2>(g, st); break; // split, 192-row tiles, 4 x 20 KB (K slabs of 16), three in flight, two per CU
         case 12: launch_ring<192, 128, 32, 0, 4, 2, 2, false, 2>(g, st); break; // bf16, 192-row tiles, 4 x 20 KB (K slabs of 32), three in flight, two per CU
         case 14: launch_ring<256, 256, 64, 0, 2, 2, 2, false, 1>(g, st); break; // bf16, FOUR waves of 128 x 128 (one per SIMD, 512-register budget), 2 x 64 KB
         case 15: launch_ring<256, 256, 32, 0, 4, 2, 2, true, 1>(g, st); break;  // bf16, four waves of 128 x 128, 4 x 32 KB, certified one ahead
         case 16: launch_ring<256, 256, 32, 1, 2, 2, 2, false, 1>(g, st); break; // split, four waves of 128 x 128, 2 x 64 KB
-        case 17: launch_ring<256, 256, 32, 1, 2, 2, 4, false>(g, st); break;    // split, 256 x 256, eight waves, 2 x 64 KB: the A panel is shared by 2 column tiles instead of 4
-        case 18: launch_ring<192, 256, 32, 1, 2, 2, 4, false>(g, st); break;    // split, 192 x 256, eight waves, 2 x 56 KB, one per CU (M = 16000, N = 768: 252 tiles on 256 CUs)
-        case 19: launch_ring<192, 256, 64, 0, 2, 2, 4, false>(g, st); break;    // bf16, 192 x 256, eight waves, 2 x 56 KB, one per CU
+        case 17: launch_ring<256, 256, 32, 1, 2, 2, 4, false>(g, st); break;    // split, 256 x 256, eight waves, 2 x 64 KB (two-stage form of ring2's 20)
+        case 18: launch_ring<192, 256, 32, 1, 2, 2, 4, false>(g, st); break;    // split, 192 x 256, eight waves, 2 x 56 KB (two-stage form of 22)
+        case 19: launch_ring<192, 256, 64, 0, 2, 2, 4, false>(g, st); break;    // bf16, 192 x 256, eight waves, 2 x 56 KB (two-stage form of 23)
         case 9: launch_ring<192, 128, 32, 1, 2, 2, 2, false, 2, true>(g, st); break;    // PROBE (wrong results): cfg 7 with 16x16x32 MFMAs
         case 10: launch_ring<192, 128, 64, 0, 2, 2, 2, false, 2, true>(g, st); break;   // PROBE (wrong results): cfg 8 with 16x16x32 MFMAs
+#endif
         default: break;
     }
 }
@@ -370,9 +369,13 @@ int ring_tile_rows(int cfg) { return ((cfg >= 7 && cfg <= 13) || cfg == 18 || cf
 int ring_tile_cols(int cfg) { return (cfg == 4 || (cfg >= 6 && cfg <= 13)) ? 128 : 256; }
 bool ring_cfg_ok(int cfg, const paa_gemm_desc& d) {
     if (cfg < 2 || cfg > 23 || cfg == 13) return false;       // 20..23: gemm_ring2.hip (separate operand rings)
+#ifdef PAA_EXPERIMENTS
     // 9 / 10 are timing probes with WRONG results (MF16): only reachable when the measurement script asks for them
     static const bool probes = getenv("PAA_MF16_PROBE") != nullptr;
     if ((cfg == 9 || cfg == 10) && !probes) return false;
+#else
+    if (cfg != 7 && cfg != 8 && cfg < 20) return false;        // the configurations the shipped library holds
+#endif
     const bool split = cfg == 4 || cfg == 6 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 20 || cfg == 22;
     if (split != (d.precision != 0)) return false;
     const int bk = (cfg == 2 || cfg == 8 || cfg == 10 || cfg == 14 || cfg == 19 || cfg == 21 || cfg == 23) ? 64 : cfg == 11 ? 16 : 32;

@@ -24,12 +24,16 @@
 
 namespace paa {
 
-// PAA_NO_BIL=1 (A/B measurements, cached by gemm.hip's environment refresh): planar weights even where B_il is given
+// -DPAA_EXPERIMENTS builds, PAA_NO_BIL=1 (A/B measurements, cached by gemm.hip): planar weights even where B_il is given
 bool gemm_env_no_bil();
 
 namespace {
 
-// 0 (diagnostic builds): every step reads its first fragments at its top instead of under the previous step's last MFMA group
+// 0 (diagnostic builds, -DPAA_EXPERIMENTS): every step reads its first fragments at its top instead of under the previous step's
+// last MFMA group
+#if defined(PAA_R2_DEFER) && !defined(PAA_EXPERIMENTS)
+#error "PAA_R2_DEFER is a diagnostic build: add -DPAA_EXPERIMENTS"
+#endif
 #ifndef PAA_R2_DEFER
 #define PAA_R2_DEFER 1
 #endif
@@ -291,19 +295,10 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     }
 }
 
-// resident workgroups of a kernel on this device (CUs x occupancy)
-template <typename K>
-int ring2_resident_blocks(K kernel, int threads) {
-    int dev = 0, cus = 0, per = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) return 0;
-    return cus * per;
-}
-
 template <int BM, int BN, int BK, int PREC, int WR, int WC, bool BIL>
 void launch_ring2_il(const GemmArgs& g, hipStream_t st) {
-    static const int resident = ring2_resident_blocks(k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL>, WR * WC * 64);
+    static const int per_cu = blocks_per_cu(k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL>, WR * WC * 64);
+    const int resident = per_cu * device_cus();
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
     hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);

@@ -104,7 +104,7 @@ struct paa_model {
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
     bool fused;                      // flash-style attention kernels (head_dim 64); else materialised scores
-    bool gate;                       // see pre16; false only in fp32-parity mode under PAA_NO_GATE32=1 (A/B measurements)
+    bool gate;                       // see pre16; false only in -DPAA_EXPERIMENTS builds under PAA_NO_GATE32=1 (fp32-parity A/B)
     bool pre16;                      // What a GELU keeps for its backward pass (L{l}.fpre, and conv{i}.pre, i < last, of the
                                      // group-norm extractor) is the derivative gelu'(v) itself in BOTH modes (paa_gemm_desc.aux_gate;
                                      // ConvL::gate): it only ever multiplies a gradient, and evaluating it next to the GELU that
@@ -174,7 +174,10 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
     m->fused = a.hidden / a.heads == 64;      // flash-style kernels; split-bf16 (hi + lo planes) in fp32-parity mode
     m->pre16 = m->prec == 0;
+    m->gate = true;
+#ifdef PAA_EXPERIMENTS      // tools/gate_ab.py: raw pre-activations in fp32-parity mode
     { const char* e = getenv("PAA_NO_GATE32"); m->gate = m->pre16 || !(e && e[0] == '1'); }
+#endif
     for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
 
     // ---- shapes: conv output lengths and the padded row counts (P_{i-1} = s_i * P_i) ----
@@ -332,8 +335,8 @@ static paa_gemm_desc gd(const paa_model* m, const float* A, const float* Bm, flo
     d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;
     return d;
 }
-// PAA_K_GROUP=0 (A/B measurements; gemm.hip caches the environment): plain K order in the strided-conv products instead of gemm.h's
-// k_group order
+// -DPAA_EXPERIMENTS builds, PAA_K_GROUP=0 (A/B measurements): plain K order in the strided-conv products instead of gemm.h's
+// k_group order; always true in the shipped library
 namespace paa { bool gemm_env_kgroup(); }
 static bool kgroup_on() { return paa::gemm_env_kgroup(); }
 // bf16-operand descriptor (every conv / linear product)

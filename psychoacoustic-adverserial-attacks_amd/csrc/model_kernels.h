@@ -66,6 +66,7 @@ paa_status conv0_dgrad_fused(const Conv0Args& a, float* part, hipStream_t st);
 paa_status conv0_ln_forward(const Conv0Args& a, hipStream_t st);
 paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, float* part, float* grad, hipStream_t st);
 int conv0_chunks(int T);
+void set_conv0_two_pass(bool on);     // paa_test_option(0, .)
 
 int64_t ctc_work_floats_per_clip(int T, int V, int S_max);
 int64_t conv0_part_floats(int B, int T, int C);

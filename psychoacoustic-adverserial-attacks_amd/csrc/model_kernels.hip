@@ -715,6 +715,9 @@ paa_status conv0_ln_forward(const Conv0Args& a, hipStream_t st) {
     return PAA_OK;
 }
 
+static bool g_conv0_two_pass = false;
+void set_conv0_two_pass(bool on) { g_conv0_two_pass = on; }
+
 paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, float* part, float* grad, hipStream_t st) {
     if (a.k > 10 || a.C > 512) PAA_FAIL(PAA_ERR_ARG, "conv0 backward: kernel %d / channels %d unsupported", a.k, a.C);
     if (layer_norm) {
@@ -724,9 +727,9 @@ paa_status conv0_backward(const Conv0Args& a, int layer_norm, int precision, flo
         PAA_LAUNCH_CHECK();
         return PAA_OK;
     }
-    // PAA_CONV0_TWO_PASS=1 (tests): keep the statistics pass + GEMM pass also in bf16 mode, to compare the two paths
-    const char* two_pass = getenv("PAA_CONV0_TWO_PASS");
-    if (conv0_dgrad_supported(a) && !(two_pass && two_pass[0] == '1')) {
+    // g_conv0_two_pass (paa_test_option(0, 1), tests only): take the statistics pass + GEMM pass — the path of the shapes the fused
+    // kernel does not cover — on every shape, so that the two can be compared on the same operands
+    if (conv0_dgrad_supported(a) && !g_conv0_two_pass) {
         // W1_b first (forward statistics only), then ONE pass over dy for G1 and the GroupNorm sums (both precision modes)
         hipLaunchKernelGGL(k_conv0_bwd_prep, dim3(a.B), dim3(256), 0, st, a, 1);
         PAA_LAUNCH_CHECK();
@@ -983,7 +986,9 @@ __global__ __launch_bounds__(256) void k_ctc_logsoftmax(const float* __restrict_
     for (int cc = c; cc < V; cc += 32) se += __expf(lg[cc] - mx);
     for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 32);
     const double lz = (double)mx + (double)__logf(se);
-    for (int cc = c; cc < V; cc += 32) lp[cc] = (double)lg[cc] - lz;
+    // a -inf logit (log-probability -inf) enters the recursion as the finite sentinel, like every other dead state: with a
+    // true -inf, max(x0, x1, x2) = -inf in ctc_lse3 makes x - m = NaN for the whole alpha / beta table
+    for (int cc = c; cc < V; cc += 32) lp[cc] = fmax((double)lg[cc] - lz, CTC_NEG);
 }
 
 // whole-wave shift by one lane through DPP (gfx9 wave_shr / wave_shl): lane i receives lane i-1 (i+1); the first (last)
@@ -1274,6 +1279,10 @@ extern "C" paa_status paa_softmax_fwd(float* s, int rows, int cols, int ld, floa
 }
 extern "C" paa_status paa_softmax_bwd(float* dp, const float* p, int rows, int cols, int ld, float scale, void* stream) {
     return softmax_bwd(dp, p, 1, rows, rows, cols, ld, scale, (hipStream_t)stream);
+}
+extern "C" paa_status paa_test_option(int option, int value) {
+    if (option == 0) { paa::set_conv0_two_pass(value != 0); return PAA_OK; }
+    PAA_FAIL(PAA_ERR_ARG, "paa_test_option: unknown option %d", option);
 }
 extern "C" int64_t paa_ctc_work_floats(int B, int T, int V, int S_max) { return (int64_t)B * ctc_work_floats_per_clip(T, V, S_max); }
 extern "C" paa_status paa_ctc(const float* logits, const int32_t* labels, int B, int T, int V, int S_max, int blank,

@@ -303,6 +303,8 @@ struct ApplyArgs {
     double numel_clean, numel_p;
     float* scal;        // [0] scale applied, [1..] diagnostics
     const float* ext;   // optional device [sum clean^2, TV(clean)] supplied by the caller (data-parallel runs)
+    const float* ext_clips;   // optional device [1]: number of clean clips over ALL ranks (an exact small integer in f32);
+    double clip_len;          //   numel_clean = ext_clips[0] * clip_len then replaces the host value above
 };
 
 template <int NORM>
@@ -314,16 +316,17 @@ __global__ __launch_bounds__(RED_NT) void k_apply_scale(float* __restrict__ p, i
     s1 = block_sum<double, RED_NT>(s1, red);
     s2 = block_sum<double, RED_NT>(s2, red);
     if (a.ext) s1 = (double)a.ext[NORM == PAA_NORM_TV ? 1 : 0];
+    const double numel_clean = a.ext_clips ? (double)a.ext_clips[0] * a.clip_len : a.numel_clean;
     float scale = 1.f;
     if (NORM == PAA_NORM_L2) {                     // projections.py:41-46 (s2 = sum p^2)
         const float norm = sqrtf((float)s2);
         if (norm > a.eps) scale = a.eps / norm;
     } else if (NORM == PAA_NORM_SNR) {             // projections.py:11-35 (s1 = sum clean^2, s2 = sum p^2)
-        const float sp = (float)(s1 / a.numel_clean);
+        const float sp = (float)(s1 / numel_clean);
         const float np_ = (float)(s2 / a.numel_p);
         const float cur = 10.f * log10f(sp / (np_ + 1e-12f));
         if (!(cur >= a.snr_db)) {
-            const float target = sqrtf(sp / a.snr_linear * (float)a.numel_clean);
+            const float target = sqrtf(sp / a.snr_linear * (float)numel_clean);
             const float cn = sqrtf((float)s2);
             if (!(cn < 1e-8f)) scale = target / cn;
         }
@@ -375,7 +378,14 @@ struct paa_proj {
 };
 
 extern "C" const char* paa_last_error(void) { return paa::g_err.c_str(); }
-extern "C" int paa_version(void) { return 100; }
+// 300 + 1 if the library was built with -DPAA_EXPERIMENTS (diagnostic configurations and environment switches present)
+extern "C" int paa_version(void) {
+#ifdef PAA_EXPERIMENTS
+    return 301;
+#else
+    return 300;
+#endif
+}
 
 extern "C" paa_status paa_proj_set_spl_thresh(paa_proj* h, const float* spl) {
     if (!h || !spl) PAA_FAIL(PAA_ERR_ARG, "paa_proj_set_spl_thresh: null argument");
@@ -523,7 +533,8 @@ extern "C" paa_status paa_istft(paa_proj* h, const float* d_S, int B, int T, flo
 
 // d_src == nullptr: in place on d_p.  Otherwise out of place: reads d_src, writes d_p (the two must not overlap).
 static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, int rows_p, const float* d_clean, int B, int L,
-                               const float* d_ext, double ext_numel, void* stream, const float* d_src = nullptr) {
+                               const float* d_ext, double ext_numel, void* stream, const float* d_src = nullptr,
+                               const float* d_ext_clips = nullptr) {
     if (!h || !prm || !d_p) PAA_FAIL(PAA_ERR_ARG, "paa_project: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int nt = prm->norm_type;
@@ -602,6 +613,7 @@ static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, i
             ApplyArgs a{};
             a.part = h->d_part; a.g1 = g1; a.g2 = g2; a.scal = h->d_scal;
             a.numel_clean = d_ext ? ext_numel : (double)nc; a.numel_p = (double)n; a.ext = d_ext;
+            a.ext_clips = d_ext ? d_ext_clips : nullptr; a.clip_len = (double)L;
             a.snr_db = prm->snr_db; a.snr_linear = (float)pow(10.0, (double)prm->snr_db / 10.0);
             a.eps = (nt == PAA_NORM_L2) ? prm->l2_size : prm->tv_epsilon;
             const int ga = std::min(cdiv(n, 256), 1024);
@@ -677,24 +689,27 @@ extern "C" paa_status paa_fm_weighted_norm(paa_proj* h, const float* d_S, int B,
 }
 
 extern "C" paa_status paa_project_ext(paa_proj* h, const paa_params* prm, float* d_p, int rows_p, const float* d_clean_stats,
-                                      double clean_numel, int L, void* stream) {
+                                      const float* d_clip_count, double clean_numel, int L, void* stream) {
     if (!d_clean_stats) PAA_FAIL(PAA_ERR_NEED_CLEAN, "paa_project_ext: clean statistics are required");
-    return project_impl(h, prm, d_p, rows_p, nullptr, 0, L, d_clean_stats, clean_numel, stream);
+    if (!d_clip_count && !(clean_numel > 0.0)) PAA_FAIL(PAA_ERR_ARG, "paa_project_ext: neither a device clip count nor a positive clean_numel");
+    return project_impl(h, prm, d_p, rows_p, nullptr, 0, L, d_clean_stats, clean_numel, stream, nullptr, d_clip_count);
 }
 
 namespace paa {
-__global__ __launch_bounds__(RED_NT) void k_sum_parts(const double* __restrict__ part, int g1, int g2, float* __restrict__ out) {
+__global__ __launch_bounds__(RED_NT) void k_sum_parts(const double* __restrict__ part, int g1, int g2, float* __restrict__ out,
+                                                      float* __restrict__ count_out, float count) {
     __shared__ double red[RED_NT / 64];
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < g1; i += RED_NT) s1 += part[i];
     for (int i = threadIdx.x; i < g2; i += RED_NT) s2 += part[g1 + i];
     s1 = block_sum<double, RED_NT>(s1, red);
     s2 = block_sum<double, RED_NT>(s2, red);
-    if (threadIdx.x == 0) { out[0] = (float)s1; out[1] = (float)s2; }
+    if (threadIdx.x == 0) { out[0] = (float)s1; out[1] = (float)s2; if (count_out) count_out[0] = count; }
 }
 }  // namespace paa
 
-extern "C" paa_status paa_batch_stats(paa_proj* h, const float* d_clean, int B, int L, float* d_out2, void* stream) {
+extern "C" paa_status paa_batch_stats(paa_proj* h, const float* d_clean, int B, int L, float* d_out2, float* d_clip_count,
+                                      void* stream) {
     if (!h || !d_clean || !d_out2) PAA_FAIL(PAA_ERR_ARG, "paa_batch_stats: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t nc = (int64_t)B * L;
@@ -705,7 +720,7 @@ extern "C" paa_status paa_batch_stats(paa_proj* h, const float* d_clean, int B, 
     hipLaunchKernelGGL(k_reduce2<RED_TV>, dim3(g), dim3(RED_NT), 0, st, d_clean, nc, L, g, (const float*)nullptr, (int64_t)0, L, 0,
                        h->d_part + g);
     PAA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(RED_NT), 0, st, (const double*)h->d_part, g, g, d_out2);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(RED_NT), 0, st, (const double*)h->d_part, g, g, d_out2, d_clip_count, (float)B);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }

@@ -382,10 +382,12 @@ __global__ __launch_bounds__(256) void k_spec_apply(SpecArgs a, int64_t n, const
 // otherwise.  4 (one hop-block per workgroup) was measured SLOWER at (1, 160000): 10.2 vs 9.1 us — four times the FFTs for
 // no shorter critical path; 12 (9 / 12 useful, two workgroups per CU) was measured slower on the batch: 84 vs 79 us at (32, 160000) —
 // the kernel is bound by its instruction stream, so the extra halo FFTs cost more than the extra waves in flight hide.  Both stay
-// reachable through PAA_SPEC_NW for experiments.
+// reachable through PAA_SPEC_NW in -DPAA_EXPERIMENTS builds.
 static int spec_nw(int T, int rows) {
+#ifdef PAA_EXPERIMENTS
     static const int force = [] { const char* e = getenv("PAA_SPEC_NW"); return e ? atoi(e) : 0; }();
     if (force == 4 || force == 8 || force == 12 || force == 16) return force;
+#endif
     return rows * cdiv(T - 1, 13) >= 256 ? 16 : 8;
 }
 
@@ -406,9 +408,11 @@ template <int OP, bool SRC_SPEC>
 paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
     switch (spec_nw(a.T, rows)) {
         case 16: return launch_fused_nw<OP, SRC_SPEC, 16>(a, rows, st);
+#ifdef PAA_EXPERIMENTS
         case 12: return launch_fused_nw<OP, SRC_SPEC, 12>(a, rows, st);
-        case 8: return launch_fused_nw<OP, SRC_SPEC, 8>(a, rows, st);
-        default: return launch_fused_nw<OP, SRC_SPEC, 4>(a, rows, st);
+        case 4: return launch_fused_nw<OP, SRC_SPEC, 4>(a, rows, st);
+#endif
+        default: return launch_fused_nw<OP, SRC_SPEC, 8>(a, rows, st);
     }
 }
 

@@ -20,18 +20,36 @@ def main(args) -> int:
         raise SystemExit("paa_amd.run_attack needs a GPU; there is no CPU fallback")
     if not str(args.device).startswith("cuda"):
         args.device = "cuda"
+    # launched by torch.distributed.run with several ranks: one process per GPU, RCCL ("nccl") over xGMI, utterances
+    # sharded over ranks; every rank keeps the same p, rank 0 writes the files
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        args.device = f"cuda:{local}"
+        if not torch.distributed.is_initialized():
+            backend = os.environ.get("PAA_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=torch.device(args.device))
+            else:
+                torch.distributed.init_process_group(backend)
+        if rank != 0:
+            args.silent = True
     logger, start_epoch = build.create_logger(args)
     logger.info("Using device: %s", args.device)
     interp = iso.build_weight_interpolator()
     spl_thresh = build.init_phon_threshold_tensor(args)
-    train_loader, eval_loader, test_loader, audio_len = build.create_data_loaders(args)
+    train_loader, eval_loader, test_loader, audio_len = build.create_data_loaders(args, rank, world)
     model, processor = build.load_model(args, max_batch=int(args.batch_size), length=audio_len)
     first = train_loader[0][0].to(args.device) if train_loader else None
     p = build.init_perturbation(args, audio_len, spl_thresh, interp, first)
+    if world > 1:          # the initial projection saw this rank's first shard only: every rank starts from rank 0's p
+        torch.distributed.broadcast(p.data, src=0)
+    writer = rank == 0
     optimizer, scheduler = (build.create_optimizer(args, p) if args.optimizer_type == "adam" else (None, None))
     hist = {k: [] for k in ("train_ctc", "train_wer", "clean_ctc", "clean_wer", "pert_ctc", "pert_wer")}
-    best_epoch, no_improve = -1, 0
-    best_eval = float("inf") if args.attack_mode == "targeted" else float("-inf")
+    goal = scoring_helpers.Objective(args.attack_mode)      # targeted: perturbed WER down; untargeted: perturbed CTC up
+    best_epoch, no_improve, best_eval = -1, 0, goal.worst
     pert_path = os.path.join(args.save_dir, "perturbation.pt")
     try:
         for epoch in range(start_epoch, int(args.num_epochs)):
@@ -46,19 +64,18 @@ def main(args) -> int:
             hist["pert_ctc"].append(pert.ctc); hist["pert_wer"].append(pert.wer)
             logger.info("[%d/%d] train ctc %.4f wer %.4f | eval clean ctc %.4f wer %.4f | eval perturbed ctc %.4f wer %.4f",
                         epoch + 1, args.num_epochs, res.avg_ctc, res.avg_wer, clean.ctc, clean.wer, pert.ctc, pert.wer)
-            mode = args.attack_mode
-            save.save_json_results(
-                save_dir=args.save_dir, norm_type=args.norm_type, attack_size=args.attack_size_string, epoch=epoch,
-                finished_training=False, eval_score_clean={"ctc": clean.ctc, "wer": clean.wer},
-                eval_score_perturbed={"ctc": scoring_helpers._best_agg(hist["pert_ctc"], mode),
-                                      "wer": scoring_helpers._best_agg(hist["pert_wer"], mode)},
-                train_score={"ctc": scoring_helpers._best_agg(hist["train_ctc"], mode),
-                             "wer": scoring_helpers._best_agg(hist["train_wer"], mode)})
-            current = pert.wer if mode == "targeted" else pert.ctc                 # run_attack.py:153
-            if scoring_helpers._is_better(current, best_eval, mode):
+            if writer:
+                save.save_json_results(
+                    save_dir=args.save_dir, norm_type=args.norm_type, attack_size=args.attack_size_string, epoch=epoch,
+                    finished_training=False, eval_score_clean={"ctc": clean.ctc, "wer": clean.wer},
+                    eval_score_perturbed={"ctc": goal.best(hist["pert_ctc"]), "wer": goal.best(hist["pert_wer"])},
+                    train_score={"ctc": goal.best(hist["train_ctc"]), "wer": goal.best(hist["train_wer"])})
+            current = pert.wer if args.attack_mode == "targeted" else pert.ctc     # run_attack.py:153
+            if goal.improves(current, best_eval):
                 no_improve, best_eval, best_epoch = 0, current, epoch
-                save.save_pert(p, pert_path)
-                save.save_by_epoch(args, p)
+                if writer:
+                    save.save_pert(p, pert_path)
+                    save.save_by_epoch(args, p)
             else:
                 no_improve += 1
             if scheduler is not None:
@@ -67,27 +84,29 @@ def main(args) -> int:
             if no_improve >= int(args.early_stopping):
                 logger.info("No improvements in %d epochs. Stopping early.", no_improve)
                 break
+        if world > 1:
+            torch.distributed.barrier()          # rank 0's last perturbation.pt is on disk
         if os.path.exists(pert_path):
             p = save.load_pert(pert_path, args.device).to(args.device)
         pert_test = evaluation.evaluate(args, test_loader, p, model, processor, None, perturbed=True)
         clean_test = evaluation.evaluate(args, test_loader, 0, model, processor, None, perturbed=False)
-        mode = args.attack_mode
-        save.save_json_results(
-            save_dir=args.save_dir, epoch=best_epoch, finished_training=True, norm_type=args.norm_type,
-            attack_size=args.attack_size_string,
-            best_train_score={"ctc": scoring_helpers._best_agg(hist["train_ctc"], mode),
-                              "wer": scoring_helpers._best_agg(hist["train_wer"], mode)},
-            eval_score_clean={"ctc": clean_test.ctc, "wer": clean_test.wer},
-            eval_score_perturbed={"ctc": pert_test.ctc, "wer": pert_test.wer},
-            final_test_clean={"ctc": clean_test.ctc, "wer": clean_test.wer},
-            final_test_perturbed={"ctc": pert_test.ctc, "wer": pert_test.wer}, best_epoch=best_epoch)
+        if writer:
+            save.save_json_results(
+                save_dir=args.save_dir, epoch=best_epoch, finished_training=True, norm_type=args.norm_type,
+                attack_size=args.attack_size_string,
+                best_train_score={"ctc": goal.best(hist["train_ctc"]), "wer": goal.best(hist["train_wer"])},
+                eval_score_clean={"ctc": clean_test.ctc, "wer": clean_test.wer},
+                eval_score_perturbed={"ctc": pert_test.ctc, "wer": pert_test.wer},
+                final_test_clean={"ctc": clean_test.ctc, "wer": clean_test.wer},
+                final_test_perturbed={"ctc": pert_test.ctc, "wer": pert_test.wer}, best_epoch=best_epoch)
         logger.info("done: best epoch %d | test clean ctc %.4f wer %.4f | test perturbed ctc %.4f wer %.4f", best_epoch,
                     clean_test.ctc, clean_test.wer, pert_test.ctc, pert_test.wer)
         return 0
     except Exception as e:      # noqa: BLE001  (run_attack.py:265-279: still leave a failure report behind)
         logger.exception("Run failed with an exception: %s", e)
         try:
-            save.save_json_results(save_dir=args.save_dir, epoch=-1, finished_training=False, norm_type=args.norm_type,
+            if rank == 0:
+                save.save_json_results(save_dir=args.save_dir, epoch=-1, finished_training=False, norm_type=args.norm_type,
                                    attack_size=args.attack_size_string, error=str(e))
         except Exception:       # noqa: BLE001
             pass

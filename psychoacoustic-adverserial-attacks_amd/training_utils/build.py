@@ -181,6 +181,24 @@ def _batches(x, texts, batch_size):
     return [(x[i:i + batch_size], texts[i:i + batch_size]) for i in range(0, len(texts), batch_size)]
 
 
+def shard_batches(batches, rank: int, world: int):
+    """Data-parallel runs: every GLOBAL batch (x (n, L), texts) is cut into ``world`` contiguous shards whose sizes
+    differ by at most one clip; rank r keeps shard r.  Ranks may therefore hold different numbers of clips in a step (the
+    packed all-reduce carries the clip count, training_utils/pgd.py); a trailing batch with fewer clips than ranks is
+    dropped, because every rank must run every step."""
+    if world <= 1:
+        return list(batches)
+    out = []
+    for x, texts in batches:
+        n = len(texts)
+        if n < world:
+            continue
+        lo = rank * n // world
+        hi = (rank + 1) * n // world
+        out.append((x[lo:hi], texts[lo:hi]))
+    return out
+
+
 def load_local_dataset(data_dir: str, sr: int):
     """A local directory of ``*.wav`` files with transcripts in ``*.trans.txt`` (LibriSpeech style: "<utt-id> TEXT")
     or ``transcripts.csv`` ("file,text").  No network, no torchaudio: PCM wav via the stdlib."""
@@ -212,10 +230,17 @@ def load_local_dataset(data_dir: str, sr: int):
     return waves, out_texts
 
 
-def create_data_loaders(args):
+def create_data_loaders(args, rank: int = 0, world: int = 1):
     """build.py:104-220 without the network: --data_dir (local wavs) or synthetic clips; fixed-length collate at the
     ``relative_audio_length`` quantile; 80/10/10 split; --small_data keeps ~1 % (at least 3 batches' worth).
-    Returns (train, eval, test) lists of (batch (B, L) float32 CPU tensor, list[str]) and the clip length."""
+    Returns (train, eval, test) lists of (batch (B, L) float32 CPU tensor, list[str]) and the clip length.
+    ``world`` > 1: global batches of ``batch_size * world`` clips, of which this rank gets its shard (``shard_batches``)."""
+    if world > 1:
+        import copy
+        g = copy.copy(args)
+        g.batch_size = int(args.batch_size) * world
+        tr, ev, te, length = create_data_loaders(g)
+        return shard_batches(tr, rank, world), shard_batches(ev, rank, world), shard_batches(te, rank, world), length
     bs = int(args.batch_size)
     data_dir = getattr(args, "data_dir", None)
     if data_dir:

@@ -7,14 +7,16 @@ utterances; because HF's CTC reduction is 'sum', the global gradient is the sum 
 gradients, so ONE all-reduce (RCCL over xGMI via torch.distributed's "nccl" backend) per step of the packed
 f32 vector
 
-    [ grad (L) | loss, sum clean^2, TV(clean), wer_errors, wer_ref_words, 0, 0, 0 ]
+    [ grad (L) | loss, sum clean^2, TV(clean), wer_errors, wer_ref_words, clips, 0, 0 ]
 
 suffices; every rank then applies the identical sign step and projection, so replicas stay bit-identical
 without a broadcast.  ``sum clean^2`` / ``TV(clean)`` are there because project_snr / project_tv use
 whole-GLOBAL-batch statistics (projections.py:11-35, 56-66); the SNR target norm also uses the global
-``clean.numel()``, which is ``L * sum of the ranks' batch sizes`` — agreed on by one small collective whenever the
-local batch size changes (a short last batch), never per step.  The WER counters are the host-side bookkeeping of
-the PREVIOUS step (train.py:149-153 runs one step behind the GPU), reduced with the same buffer.
+``clean.numel()`` = ``L * sum of the ranks' batch sizes``: every rank writes its own clip count into slot 5 each step
+(``paa_batch_stats``), the all-reduce sums it (a small integer, exact in f32) and ``paa_project_ext`` reads the sum on the
+device — so ranks may hold different numbers of clips, in any step, without a collective of their own.  The WER counters
+are the host-side bookkeeping of the PREVIOUS step (train.py:149-153 runs one step behind the GPU), reduced with the same
+buffer.  The layout of the 8 slots is defined HERE (ST_*) and documented in include/paa_hip.h (paa_model_fwd_bwd, d_stats).
 """
 from __future__ import annotations
 
@@ -24,11 +26,13 @@ from .. import _lib, runtime
 
 FREQ_NORMS = ("fletcher_munson", "min_max_freqs", "max_phon")
 N_STATS = 8
-ST_LOSS, ST_SQ, ST_TV, ST_WER_ERR, ST_WER_REF = 0, 1, 2, 3, 4
+ST_LOSS, ST_SQ, ST_TV, ST_WER_ERR, ST_WER_REF, ST_CLIPS = 0, 1, 2, 3, 4, 5
 
 
 class PgdStepper:
-    def __init__(self, model, args, length: int, interp=None, spl_thresh=None, group=None):
+    def __init__(self, model, args, length: int, interp=None, spl_thresh=None, group=None, force_collective=False):
+        """``force_collective``: run the packed all-reduce (and the global-statistics projection) even with a single rank —
+        the way the one-GPU test box executes the RCCL branch (tests/test_gpu_rccl.py)."""
         self.model, self.args, self.L = model, args, int(length)
         self.dev = model.device
         self.norms = str(args.norm_type).split("+")
@@ -46,17 +50,18 @@ class PgdStepper:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(group)
-        self.need_clean_stats = self.world > 1 and any(n in ("snr", "tv") for n in self.norms)
+        self.collective = self.world > 1 or bool(force_collective)
+        if self.collective and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise RuntimeError("force_collective needs an initialised torch.distributed process group")
+        self.need_clean_stats = self.collective and any(n in ("snr", "tv") for n in self.norms)
         self._prm = []
         for n in self.norms:
             a = type("A", (), dict(vars(args)))()
             a.norm_type = n
             self._prm.append(runtime.params_of(a))
-        self._wer_ring = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(4)] if self.world > 1 else None
+        self._wer_ring = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(4)] if self.collective else None
         self._wer_i = 0
         self._wer_next = (0.0, 0.0)
-        self._shard_B = None           # local batch size the global element count below was agreed for
-        self._global_numel = None
 
     # ---- bookkeeping carried by the packed vector -------------------------------------------------------------
     def set_wer_counts(self, errors: float, ref_words: float):
@@ -67,20 +72,13 @@ class PgdStepper:
     def _push_wer(self):
         """This rank's WER counters of the previous step go behind the gradient (pinned ring: the copy is asynchronous,
         so a slot must stay untouched until the GPU has consumed it)."""
-        if self.world == 1:
+        if not self.collective:
             return
         h = self._wer_ring[self._wer_i & 3]
         self._wer_i += 1
         h[0], h[1] = self._wer_next
         self._wer_next = (0.0, 0.0)
         self.stats[ST_WER_ERR:ST_WER_REF + 1].copy_(h, non_blocking=True)
-
-    def _sync_shards(self, B: int):
-        """Collective, only when the local batch size changes: global clean.numel() = L * sum_r B_r."""
-        t = torch.tensor([float(B)], dtype=torch.float64, device=self.dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)
-        self._global_numel = float(t.item()) * self.L
-        self._shard_B = B
 
     # ---- the two halves of a step (everything before / after the collective) ----------------------------------
     def _pre(self, p, clean, labels, want_logits=True, logits_out=None):
@@ -91,8 +89,8 @@ class PgdStepper:
         r = self.model.fwd_bwd(clean, p, labels, self.direction, want_grad=True, want_logits=want_logits, out=out)
         if self.need_clean_stats:
             with torch.cuda.device(self.dev):
-                _lib.check(_lib.lib().paa_batch_stats(self.proj.h, _lib.ptr(clean), B, self.L,
-                                                      _lib.ptr(self.stats[ST_SQ:ST_TV + 1]), _lib.stream_ptr()))
+                _lib.check(_lib.lib().paa_batch_stats(self.proj.h, _lib.ptr(clean), B, self.L, _lib.ptr(self.stats[ST_SQ:ST_TV + 1]),
+                                                      _lib.ptr(self.stats[ST_CLIPS:ST_CLIPS + 1]), _lib.stream_ptr()))
         return r
 
     def _post(self, p, clean):
@@ -103,7 +101,7 @@ class PgdStepper:
             for n, prm in zip(self.norms, self._prm):                                                   # train.py:162
                 if self.need_clean_stats and n in ("snr", "tv"):
                     _lib.check(lib.paa_project_ext(self.proj.h, prm, _lib.ptr(p), 1, _lib.ptr(self.stats[ST_SQ:ST_TV + 1]),
-                                                   self._global_numel, L, st))
+                                                   _lib.ptr(self.stats[ST_CLIPS:ST_CLIPS + 1]), 0.0, L, st))
                 else:
                     _lib.check(lib.paa_project(self.proj.h, prm, _lib.ptr(p), 1, _lib.ptr(clean), B, L, st))
 
@@ -113,11 +111,9 @@ class PgdStepper:
         clean = runtime.as_f32_cuda(clean, "clean_audio")
         if p.numel() != self.L or clean.shape[-1] != self.L:
             raise ValueError(f"Loaded perturbation length {p.numel()} / clip length {clean.shape[-1]} != expected {self.L}")
-        if self.need_clean_stats and clean.shape[0] != self._shard_B:
-            self._sync_shards(clean.shape[0])
         self._push_wer()
         r = self._pre(p, clean, labels, want_logits, logits_out)
-        if self.world > 1:
+        if self.collective:
             torch.distributed.all_reduce(self.packed, op=torch.distributed.ReduceOp.SUM, group=self.group)
         self._post(p, clean)
         r["loss"] = self.stats[ST_LOSS]
@@ -136,7 +132,7 @@ class PgdStepper:
         with torch.cuda.stream(s):                       # warm-up on the side stream, as torch's capture rules require
             self.step(p, clean, lab, logits_out=logits_out)
         torch.cuda.current_stream(self.dev).wait_stream(s)
-        if self.world == 1:
+        if not self.collective:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 r = self.step(p, clean, lab, logits_out=logits_out)

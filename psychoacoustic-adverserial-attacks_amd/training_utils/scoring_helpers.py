@@ -1,24 +1,45 @@
-"""Best-score bookkeeping — reference ``src/training_utils/scoring_helpers.py`` (with its missing import fixed)."""
-from dataclasses import dataclass
+"""Which of two scores is "better" depends on the attack: a targeted run wants the perturbed WER (against the
+target string) DOWN, an untargeted run wants the perturbed CTC loss UP.  ``Objective`` folds that into one signed
+comparison; the three names the reference's runner imports from its ``training_utils/scoring_helpers.py``
+(``Scores``, ``_is_better``, ``_best_agg``) are kept as thin views of it so that callers written against the reference
+keep working."""
+from __future__ import annotations
+
+import math
+from typing import Iterable, NamedTuple
 
 
-@dataclass(frozen=True)
-class Scores:
+class Scores(NamedTuple):
+    """(ctc, wer) pair returned by ``evaluation.evaluate``."""
     ctc: float
     wer: float
 
 
+class Objective:
+    """sense = +1: larger is better (untargeted), -1: smaller is better (targeted)."""
+    _SENSE = {"untargeted": +1.0, "targeted": -1.0}
+
+    def __init__(self, attack_mode: str):
+        if attack_mode not in self._SENSE:
+            raise ValueError(f"Unknown attack_mode: {attack_mode!r}")
+        self.sense = self._SENSE[attack_mode]
+
+    @property
+    def worst(self) -> float:
+        """The value every real score beats: -inf when maximising, +inf when minimising."""
+        return -self.sense * math.inf
+
+    def improves(self, candidate: float, incumbent: float) -> bool:
+        """Strictly better; NaN never improves and ties do not count."""
+        return self.sense * candidate > self.sense * incumbent
+
+    def best(self, history: Iterable[float]) -> float:
+        return max(history, key=lambda v: self.sense * v, default=self.worst)
+
+
 def _is_better(curr: float, best: float, mode: str) -> bool:
-    """Targeted: lower perturbed WER is better; untargeted: higher perturbed CTC loss is better (scoring_helpers.py:6-17)."""
-    if mode == "targeted":
-        return curr < best
-    if mode == "untargeted":
-        return curr > best
-    raise ValueError(f"Unknown attack_mode: {mode!r}")
+    return Objective(mode).improves(curr, best)
 
 
 def _best_agg(values, mode: str) -> float:
-    """Min for targeted, max for untargeted (scoring_helpers.py:19-23)."""
-    if not values:
-        return float("inf") if mode == "targeted" else float("-inf")
-    return (min if mode == "targeted" else max)(values)
+    return Objective(mode).best(values)

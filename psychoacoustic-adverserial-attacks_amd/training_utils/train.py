@@ -30,6 +30,19 @@ def _avg(values: Iterable[float]) -> float:
     return sum(vals) / max(len(vals), 1)
 
 
+def global_wer_per_step(counts, device, group=None):
+    """Data-parallel runs: ``counts`` = this rank's [(word errors, reference words)] per step.  The WER the reference would
+    report for the GLOBAL batch of a step is sum_r errors / sum_r words (jiwer is corpus-level within a batch), so the
+    per-step counts of all ranks are summed by ONE small all-reduce at the end of the epoch (every rank runs the same
+    number of steps — the step's own all-reduce already requires that)."""
+    import torch.distributed as dist
+    t = torch.tensor(counts, dtype=torch.float64, device=device).reshape(-1, 2)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t = t.cpu()
+    return [float(e) / max(float(w), 1.0) for e, w in t.tolist()]
+
+
 def perturbation_constraint(p: torch.Tensor, clean_audio, args, interp, spl_thresh) -> torch.Tensor:
     """train.py:69-99.  Returns a new tensor; ``p`` is left untouched.  ``args.norm_type`` may be a
     '+'-joined list (extension, applied in the written order)."""
@@ -70,7 +83,7 @@ def perturbation_constraint(p: torch.Tensor, clean_audio, args, interp, spl_thre
 def train_epoch(args, train_data_loader, p: torch.Tensor, model, epoch: int, processor, interp, wer_metric,
                 spl_thresh, optimizer) -> TrainEpochResult:
     """train.py:103-182.  ``model`` is a ``paa_amd.model.PaaModel``."""
-    ctc_scores, wer_scores, times = [], [], []
+    ctc_scores, wer_scores, wer_counts, times = [], [], [], []
     logger.info("starting epoch: %d", epoch)
     if args.optimizer_type not in ("pgd", "adam"):
         raise NotImplementedError(f"Optimization type not implemented: {args.optimizer_type!r}")   # train.py:177
@@ -81,6 +94,8 @@ def train_epoch(args, train_data_loader, p: torch.Tensor, model, epoch: int, pro
     if stepper is None or stepper.args is not args or stepper.L != L:
         stepper = PgdStepper(model, args, L, interp, spl_thresh)
         model._stepper = stepper
+    if args.optimizer_type == "adam" and stepper.world > 1:
+        raise NotImplementedError("the Adam branch runs on one GPU; the data-parallel step is the PGD branch (SURVEY 8e)")
     for clean_audio, target_texts in train_data_loader:
         t0 = time.perf_counter()
         clean_audio = clean_audio.to(args.device, torch.float32, non_blocking=True).contiguous()   # train.py:129
@@ -99,7 +114,13 @@ def train_epoch(args, train_data_loader, p: torch.Tensor, model, epoch: int, pro
             with torch.no_grad():
                 p.data = perturbation_constraint(p.data, clean_audio, args, interp, spl_thresh)   # train.py:172-175
         ctc_scores.append(float(r["loss"].item()))                                   # train.py:146
-        wer = loss_helpers.compute_wer(r["logits"], target_texts, processor, wer_metric)   # train.py:149-153
-        wer_scores.append(float(wer))
+        pred_texts, ref_texts = loss_helpers.wer_texts(r["logits"], target_texts, processor)       # train.py:149-153
+        e, w = loss_helpers.wer_counts(pred_texts, ref_texts)
+        wer_counts.append((e, w))
+        stepper.set_wer_counts(e, w)          # rides behind the next step's gradient (stats[3:5] = sums over ranks)
+        wer_scores.append(float(wer_metric.compute(predictions=pred_texts, references=ref_texts)) if wer_metric is not None
+                          else e / max(w, 1))
         times.append(time.perf_counter() - t0)
+    if stepper.world > 1:                     # the loss in stats[0] is already the global batch's; make the WER global too
+        wer_scores = global_wer_per_step(wer_counts, stepper.dev, stepper.group)
     return TrainEpochResult(p=p, avg_ctc=_avg(ctc_scores), avg_wer=_avg(wer_scores))

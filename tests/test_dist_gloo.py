@@ -41,17 +41,18 @@ def _project_global(p, args, stats, numel):
     return p * (eps / tv) if tv > eps else p
 
 
-def _worker(rank, world, port, norm, q):
+def _worker(rank, world, port, norm, q, sizes=(2, 2)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     a = A.tiny()
-    B, L = 2, 8000                      # clips per rank
+    B, L = sizes[rank], 8000            # clips of THIS rank (ranks may differ: a short last global batch)
+    first = sum(sizes[:rank])
     args = OP.default_args(norm_type=norm, snr_db=40.0, tv_epsilon=0.001)
     sd = OW.to_torch(A.rule_weights(a))
-    clean = torch.from_numpy(synth.clean_audio(B, L, first_clip=rank * B))
-    texts = ["ab cd", "hello", "a b c", "xyz w"][rank * B:(rank + 1) * B]
+    clean = torch.from_numpy(synth.clean_audio(B, L, first_clip=first))
+    texts = ["ab cd", "hello", "a b c", "xyz w"][first:first + B]
     labels = opgd.make_labels(texts, args, B)
     p = torch.from_numpy(synth.perturbation(L) * np.float32(1e-2))
     pr = p.clone().requires_grad_(True)
@@ -62,10 +63,11 @@ def _worker(rank, world, port, norm, q):
     packed[L] = loss.detach()
     packed[L + 1] = (clean ** 2).sum()
     packed[L + 2] = (clean[:, 1:] - clean[:, :-1]).abs().sum()
+    packed[L + 5] = float(B)            # slot 5: this rank's clip count (training_utils/pgd.py ST_CLIPS)
     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     with torch.no_grad():
         p_new = p + args.lr * packed[:L].sign()[None]
-        p_new = _project_global(p_new, args, packed[L:], float(world * B * L))
+        p_new = _project_global(p_new, args, packed[L:], float(packed[L + 5]) * L)     # global clean.numel() from the SAME all-reduce
     gathered = [torch.zeros_like(p_new) for _ in range(world)]
     dist.all_gather(gathered, p_new)
     if rank == 0:
@@ -73,13 +75,15 @@ def _worker(rank, world, port, norm, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("norm", ["snr", "tv"])
-def test_two_rank_step_equals_full_batch(norm):
+@pytest.mark.parametrize("norm,sizes", [("snr", (2, 2)), ("tv", (2, 2)), ("snr", (3, 1))])
+def test_two_rank_step_equals_full_batch(norm, sizes):
+    """sizes = clips per rank; (3, 1) is the short-last-batch case: no collective other than the one packed all-reduce may
+    depend on the local batch size (a per-rank 'batch size changed' collective deadlocks there)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, norm, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, norm, q, sizes)) for r in range(world)]
     for pr in procs:
         pr.start()
     p_dp, loss_dp, identical = q.get(timeout=240)

@@ -108,6 +108,11 @@ def test_scoring_helpers():
     assert scoring_helpers._best_agg([], "targeted") == float("inf")
     with pytest.raises(ValueError):
         scoring_helpers._is_better(1, 2, "sideways")
+    up, down = scoring_helpers.Objective("untargeted"), scoring_helpers.Objective("targeted")
+    assert up.worst == float("-inf") and down.worst == float("inf")
+    assert not up.improves(float("nan"), 0.0) and not down.improves(float("nan"), 0.0)
+    assert not up.improves(1.0, 1.0) and up.improves(float("inf"), up.worst) and not up.improves(up.worst, up.worst)
+    assert scoring_helpers._best_agg([], "untargeted") == float("-inf")
 
 
 def test_results_json_equals_reference_writer(tmp_path, gold):

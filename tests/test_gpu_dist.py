@@ -19,7 +19,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, norm, q):
+TEXTS = ["ab cd", "hello", "a b c", "xyz w"]
+
+
+def _worker(rank, world, port, norm, q, sizes=(2, 2), graph=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from oracle import pgd as opgd
@@ -30,17 +33,26 @@ def _worker(rank, world, port, norm, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     a = A.tiny()
-    B, L = 2, 8000
+    B, L = sizes[rank], 8000                 # ranks may hold different numbers of clips (short last global batch)
+    first = sum(sizes[:rank])
     args = cli_to_args(norm, ["--snr_db", "40"] if norm == "snr" else [])
     args.device = "cuda"
-    texts = ["ab cd", "hello", "a b c", "xyz w"][rank * B:(rank + 1) * B]
-    clean = torch.from_numpy(synth.clean_audio(B, L, first_clip=rank * B)).cuda()
+    texts = TEXTS[first:first + B]
+    clean = torch.from_numpy(synth.clean_audio(B, L, first_clip=first)).cuda()
     p = torch.from_numpy(synth.perturbation(L) * np.float32(1e-2)).cuda()
     m = PaaModel(a, A.rule_weights(a), B, L, "fp32")
     st = PgdStepper(m, args, L)
-    assert st.world == world
-    for _ in range(2):
-        r = st.step(p, clean, opgd.make_labels(texts, args, B))
+    assert st.world == world and st.collective
+    labels = opgd.make_labels(texts, args, B)
+    if graph:                                # the two-graph form: replay = graph 1, all-reduce, graph 2
+        p0 = p.clone()
+        g, r = st.capture(p, clean, labels)
+        p.copy_(p0)
+        for _ in range(2):
+            g.replay()
+    else:
+        for _ in range(2):
+            r = st.step(p, clean, labels)
     torch.cuda.synchronize()
     out = [torch.zeros_like(p) for _ in range(world)]
     dist.all_gather(out, p)
@@ -49,8 +61,11 @@ def _worker(rank, world, port, norm, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("norm", ["snr", "max_phon"])
-def test_two_ranks_equal_one(norm):
+@pytest.mark.parametrize("norm,sizes,graph", [("snr", (2, 2), False), ("max_phon", (2, 2), False), ("snr", (3, 1), False),
+                                              ("tv", (1, 3), False), ("snr", (2, 2), True), ("snr", (3, 1), True)])
+def test_two_ranks_equal_one(norm, sizes, graph):
+    """sizes: clips per rank — unequal shards must work with the ONE packed all-reduce (the clip count rides in slot 5);
+    graph: the step replayed from PgdStepper.capture's two-graph form (_SplitGraph) instead of launched eagerly."""
     from oracle import pgd as opgd
     from oracle.gen_cases import cli_to_args
     from paa_amd import arch as A, synth
@@ -59,7 +74,7 @@ def test_two_ranks_equal_one(norm):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, norm, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, norm, q, sizes, graph)) for r in range(2)]
     for pr in procs:
         pr.start()
     p_dp, loss_dp, identical = q.get(timeout=300)
@@ -76,7 +91,7 @@ def test_two_ranks_equal_one(norm):
     m = PaaModel(a, A.rule_weights(a), B, L, "fp32")
     st = PgdStepper(m, args, L)
     for _ in range(2):
-        r = st.step(p, clean, opgd.make_labels(["ab cd", "hello", "a b c", "xyz w"], args, B))
+        r = st.step(p, clean, opgd.make_labels(TEXTS, args, B))
     torch.cuda.synchronize()
     assert loss_dp == pytest.approx(float(r["loss"]), rel=1e-5)
     diff = np.abs(p_dp - p.cpu().numpy())

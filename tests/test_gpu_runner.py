@@ -62,3 +62,50 @@ def test_evaluation_forward_no_clamp():
     r0 = m.forward(clean.cuda(), None, labels)
     ref0, _ = OW.forward(OW.to_torch(sdn), a, clean, labels)
     assert abs(float(r0["loss"]) - float(ref0)) < 1e-4 * abs(float(ref0))
+
+
+@pytest.mark.parametrize("norm,stable", [("group", False), ("layer", True)])
+def test_load_model_from_local_checkpoint(tmp_path, norm, stable):
+    """Row (g): the reference loads its model by name (src/training_utils/build.py:225-231, from_pretrained); here --model_path
+    names a LOCAL HuggingFace checkpoint directory.  A tiny Wav2Vec2ForCTC of each topology is written with save_pretrained
+    (config.json + safetensors, plus the tokenizer / feature-extractor files of a Wav2Vec2Processor) and loaded back through
+    build.load_model: architecture mapping, weight packing (parametrised weight-norm keys) and the processor must all come from the
+    files — logits equal to the model built from the same weights directly (bit for bit) and to HF's own forward (fp32-parity
+    tolerance); labels through the loaded processor equal to the built-in tokenizer's."""
+    pytest.importorskip("transformers")
+    import json as js
+    from transformers import Wav2Vec2CTCTokenizer, Wav2Vec2FeatureExtractor, Wav2Vec2Processor
+    from hf_util import hf_model
+    from paa_amd.core import loss_helpers
+    from paa_amd.training_utils import build
+    a = A.tiny(norm, stable)
+    sdn = A.rule_weights(a)
+    hf = hf_model(a, sdn)
+    ck = tmp_path / "ckpt"
+    hf.save_pretrained(str(ck))
+    vp = tmp_path / "vocab.json"
+    vp.write_text(js.dumps({t: i for i, t in enumerate(loss_helpers.VOCAB)}))
+    tok = Wav2Vec2CTCTokenizer(str(vp), unk_token="<unk>", pad_token="<pad>", word_delimiter_token="|")
+    Wav2Vec2Processor(feature_extractor=Wav2Vec2FeatureExtractor(), tokenizer=tok).save_pretrained(str(ck))
+    B, L = 2, 8000
+    args = parser.create_arg_parser().parse_args(["--model_path", str(ck), "--dtype", "fp32", "--device", "cuda", "--norm_type", "snr",
+                                                  "--optimizer_type", "pgd"])
+    m, proc = build.load_model(args, max_batch=B, length=L)
+    assert m.arch == a and proc is not None
+    texts = ["hello world it's", "a <unk> b"]
+    lab_proc = loss_helpers.make_labels(texts, proc, args, B)
+    lab_own = loss_helpers.make_labels(texts, None, args, B)
+    assert torch.equal(lab_proc, lab_own)
+    clean = torch.from_numpy(synth.clean_audio(B, L)).cuda()
+    p = torch.from_numpy(synth.perturbation(L) * np.float32(1e-2)).cuda()
+    got = m.fwd_bwd(clean, p, lab_proc, +1)
+    direct = PaaModel(a, sdn, B, L, "fp32").fwd_bwd(clean, p, lab_own, +1)
+    torch.cuda.synchronize()
+    assert torch.equal(got["logits"], direct["logits"]) and torch.equal(got["grad"], direct["grad"])
+    with torch.no_grad():
+        ref = hf(input_values=(clean.cpu() + p.cpu()).clamp(-1, 1), labels=lab_own)
+    assert rel_err(got["logits"].cpu().numpy(), ref.logits.numpy()) < 1e-3
+    assert abs(float(got["loss"]) - float(ref.loss)) < 2e-4 * abs(float(ref.loss))
+    # and the runner end to end on that checkpoint
+    rc, rargs = _run(tmp_path / "logs", ["--optimizer_type", "pgd", "--norm_type", "linf", "--model_path", str(ck), "--num_epochs", "1"])
+    assert rc == 0 and json.load(open(os.path.join(rargs.save_dir, "results.json")))["finished_training"] == 1.0

@@ -109,3 +109,71 @@ def test_pos_conv_weight_key_aliases():
     import pytest
     with pytest.raises(KeyError):
         A.pos_conv_weight({})
+
+
+# ---- row (g): local-checkpoint loading (src/training_utils/build.py:225-231 loads Wav2Vec2ForCTC by name; here a LOCAL directory) ----
+def test_arch_from_hf_config_both_topologies():
+    """The two published topologies, as their config.json files describe them: wav2vec2-base-960h is Wav2Vec2Config's default
+    (group-norm extractor without conv bias, post-LN encoder); wav2vec2-large-960h-lv60-self is the layer-norm extractor with conv
+    bias and the pre-LN ("stable") encoder.  A wrong feat_extract_norm / do_stable_layer_norm mapping would pick the wrong kernels."""
+    pytest.importorskip("transformers")
+    from transformers import Wav2Vec2Config
+    from paa_amd.model import arch_from_hf_config, arch_struct
+    assert arch_from_hf_config(Wav2Vec2Config()) == A.BASE
+    large = Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, conv_bias=True,
+                           feat_extract_norm="layer", do_stable_layer_norm=True)
+    assert arch_from_hf_config(large) == A.LARGE_LV60
+    s = arch_struct(arch_from_hf_config(large))
+    assert (s.feat_norm_layer, s.stable_ln, s.conv_bias, s.hidden, s.layers, s.heads, s.ffn) == (1, 1, 1, 1024, 24, 16, 4096)
+    s = arch_struct(arch_from_hf_config(Wav2Vec2Config()))
+    assert (s.feat_norm_layer, s.stable_ln, s.conv_bias, s.hidden, s.layers, s.heads, s.ffn, s.vocab, s.blank) == (0, 0, 0, 768, 12, 12, 3072, 32, 0)
+    assert list(s.conv_kernel)[:7] == [10, 3, 3, 3, 3, 2, 2] and list(s.conv_stride)[:7] == [5, 2, 2, 2, 2, 2, 2]
+
+
+@pytest.mark.parametrize("norm,stable", [("group", False), ("layer", True)])
+def test_pack_weights_of_hf_state_dict(norm, stable):
+    """pack_weights over an HF module's own state_dict() — parametrised weight-norm keys (torch >= 2.1) and the weight_g / weight_v
+    names of the published checkpoint files — equals pack_weights over the rule weights the module was loaded from, and the folded
+    positional-conv weight equals the one HF's module computes."""
+    pytest.importorskip("transformers")
+    from hf_util import hf_model
+    from paa_amd.arch import pos_conv_weight
+    from paa_amd.model import arch_from_hf_config
+    a = A.tiny(norm, stable)
+    sd = A.rule_weights(a)
+    hf = hf_model(a, sd)
+    assert arch_from_hf_config(hf.config) == a
+    ref = pack_weights(a, sd)
+    hsd = {k: v.detach().numpy() for k, v in hf.state_dict().items()}
+    pc = "wav2vec2.encoder.pos_conv_embed.conv"
+    assert f"{pc}.parametrizations.weight.original0" in hsd or f"{pc}.weight_g" in hsd
+    legacy = {k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v"): v
+              for k, v in hsd.items()}
+    assert f"{pc}.weight_g" in legacy and f"{pc}.weight_v" in legacy
+    for name, d in (("hf", hsd), ("legacy", legacy)):
+        got = pack_weights(arch_from_hf_config(hf.config), d)
+        assert got.keys() == ref.keys(), name
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{name}:{k}")
+    np.testing.assert_allclose(pos_conv_weight(hsd), hf.wav2vec2.encoder.pos_conv_embed.conv.weight.detach().numpy(), rtol=2e-6, atol=1e-7)
+    with pytest.raises(KeyError):
+        pos_conv_weight({k: v for k, v in hsd.items() if "pos_conv_embed" not in k})
+
+
+def test_shard_batches_and_objective():
+    """build.shard_batches: contiguous shards whose sizes differ by at most one clip, together covering every global batch; a batch
+    with fewer clips than ranks is dropped on every rank."""
+    from paa_amd.training_utils import build
+    batches = [(torch.arange(7 * 3).reshape(7, 3).float(), [f"t{i}" for i in range(7)]),
+               (torch.arange(2 * 3).reshape(2, 3).float(), ["a", "b"])]
+    for world in (1, 2, 3):
+        shards = [build.shard_batches(batches, r, world) for r in range(world)]
+        n_steps = {len(s) for s in shards}
+        assert len(n_steps) == 1                                   # every rank runs the same number of steps
+        for step in range(n_steps.pop()):
+            xs = torch.cat([s[step][0] for s in shards])
+            ts = sum((s[step][1] for s in shards), [])
+            assert torch.equal(xs, batches[step][0]) and ts == batches[step][1]
+            sizes = [len(s[step][1]) for s in shards]
+            assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    assert len(build.shard_batches(batches, 0, 3)) == 1            # the 2-clip batch cannot feed 3 ranks
