@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpaa_hip.so")
+# PAA_EXTRA_HIPCC_FLAGS (tools/ only: diagnostic builds, see build_ext.py) selects the diagnostic library built next to the shipped one
+LIB_PATH = os.path.join(HERE, "libpaa_hip_exp.so" if os.environ.get("PAA_EXTRA_HIPCC_FLAGS", "").strip() else "libpaa_hip.so")
 
 ABI_VERSIONS = (300, 301)      # include/paa_hip.h paa_version: 301 = the same ABI built with -DPAA_EXPERIMENTS
 
@@ -49,7 +50,8 @@ class PaaGemmDesc(C.Structure):
                 ("res_s2", C.c_int64), ("row_period", C.c_int32), ("row_valid", C.c_int32),
                 ("accumulate", C.c_int32), ("precision", C.c_int32),
                 ("operand_bf16", C.c_int32), ("A_lo", C.c_void_p), ("B_lo", C.c_void_p), ("Cb", C.c_void_p),
-                ("Cb_lo", C.c_void_p), ("aux_bf16", C.c_int32), ("aux_gate", C.c_int32), ("k_group", C.c_int32), ("B_il", C.c_void_p)]
+                ("Cb_lo", C.c_void_p), ("aux_bf16", C.c_int32), ("aux_gate", C.c_int32), ("k_group", C.c_int32), ("B_il", C.c_void_p),
+                ("A_il", C.c_void_p), ("Cb_il", C.c_void_p)]
 
 
 _SIGS = {
@@ -122,7 +124,7 @@ def _check_current():
     spec = importlib.util.spec_from_file_location("paa_build_ext", os.path.join(HERE, "build_ext.py"))
     be = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(be)
-    if os.environ.get("PAA_EXTRA_HIPCC_FLAGS") is None and not be.is_current():
+    if not be.is_current():
         raise RuntimeError(f"{LIB_PATH} was not built from the sources in {be.CSRC} (content hash mismatch): run "
                            "`python __graft_entry__.py build`")
 

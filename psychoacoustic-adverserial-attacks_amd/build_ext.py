@@ -15,10 +15,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-LIB = os.path.join(HERE, "libpaa_hip.so")
 SOURCES = ["proj_kernels.hip", "spec_kernels.hip", "gemm.hip", "gemm_ring.hip", "gemm_ring2.hip", "model_kernels.hip", "conv0_dgrad.hip", "attention.hip", "model.hip"]
 # PAA_EXTRA_HIPCC_FLAGS: diagnostic builds of tools/ (e.g. "-DPAA_EXPERIMENTS -DPAA_ABL=3"); never set by __graft_entry__.build()
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value"] + os.environ.get("PAA_EXTRA_HIPCC_FLAGS", "").split()
+# a diagnostic build lives NEXT to the shipped library (its own file and object directory), never in its place
+VARIANT = "_exp" if os.environ.get("PAA_EXTRA_HIPCC_FLAGS", "").strip() else ""
+LIB = os.path.join(HERE, f"libpaa_hip{VARIANT}.so")
 
 
 def _hipcc() -> str:
@@ -69,7 +71,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     key = source_key()
     if not force and os.path.exists(LIB) and _read(LIB + ".key") == key:
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + VARIANT)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hdrs = _headers()

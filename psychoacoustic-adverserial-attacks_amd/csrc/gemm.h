@@ -79,6 +79,17 @@ typedef struct paa_gemm_desc {
     // row is one full 128-byte line instead of one 64-byte segment in each plane (half the L2 requests).  Kernels that do not
     // take this layout read B / B_lo as before; both must be given.
     const void* B_il;
+    // A_il != NULL (precision 1, operand_bf16, plain K-contiguous rows: no a_kseg / a_window): the A operand's two planes live in ONE
+    // array interleaved per 32-element K group — element (m, k): hi at A_il[m * 2 lda + (k / 32) * 64 + k % 32], lo 32 elements
+    // further; batch offsets are 2 (z1 a_s1 + z2 a_s2).  lda, a_s1, a_s2 and K must be multiples of 32 (lda stays the row stride in
+    // ELEMENTS of the logical matrix; overlapping conv windows work as before, a window of k taps being 2 k C consecutive array
+    // elements).  A and A_lo are ignored.  A K slab of a row is then one full 128-byte line instead of a 64-byte segment in each of two
+    // planes: half the requests on the operand that streams from HBM.  The producer of such a tensor writes it with Cb_il (or
+    // paa::Bf::il in the element-wise kernels).
+    const void* A_il;
+    // Cb_il != NULL (precision 1): the bf16 result goes to ONE interleaved array instead of Cb / Cb_lo (which must be NULL):
+    // hi of (m, n) at Cb_il[2 (z1 c_s1 + z2 c_s2) + m * 2 ldc + (n / 32) * 64 + n % 32], lo 32 further; ldc, c_s1, c_s2 multiples of 32.
+    void* Cb_il;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

@@ -215,11 +215,12 @@ __global__ __launch_bounds__(G_NT) void k_gemm(GemmArgs g) {
 constexpr int H_BK = 64, H_LD = 72;
 
 // General loader (SEG kernels): segmented K and the zero-filled time window of the grouped positional convolution.
+// il (A operand only, gemm.h A_il): 0 = planar; 1 / 2 = the hi / lo part of an interleaved array (`base` = the array, `ld` = 2 lda)
 template <int ROWS, bool IS_A, int NT>
 __device__ __forceinline__ void load_bf(const paa_gemm_desc& d, const unsigned short* __restrict__ base, int64_t ld,
-                                        int r0, int k0, int rlim, uint4 (&v)[ROWS * 8 / NT], int tid) {
+                                        int r0, int k0, int rlim, uint4 (&v)[ROWS * 8 / NT], int tid, int il = 0) {
     const int k = k0 + ((tid & 7) << 3);
-    int64_t koff = k;
+    int64_t koff = il ? ((k >> 5) << 6) + (k & 31) + (il == 2 ? 32 : 0) : k;
     int js = 0, kc = k;
     if (IS_A && d.a_kseg > 0) {
         js = k / d.a_kseg;
@@ -322,11 +323,29 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
     auto load_tile = [&](const Tile& c, int k0, int tid) {
         const int64_t aoff = c.z1 * d.a_s1 + c.z2 * d.a_s2, boff = c.z1 * d.b_s1 + c.z2 * d.b_s2;
         if constexpr (SEG) {
-            load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A) + aoff, d.lda, c.m0, k0, d.M, rah, tid);
+            const bool ail = PREC && d.A_il != nullptr;
+            if (ail) load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A_il) + 2 * aoff, 2 * d.lda, c.m0, k0, d.M, rah, tid, 1);
+            else load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A) + aoff, d.lda, c.m0, k0, d.M, rah, tid);
             load_bf<BN, false, NT>(d, reinterpret_cast<const unsigned short*>(d.B) + boff, d.ldb, c.n0, k0, d.N, rbh, tid);
             if constexpr (PREC) {
-                load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A_lo) + aoff, d.lda, c.m0, k0, d.M, ral, tid);
+                if (ail) load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A_il) + 2 * aoff, 2 * d.lda, c.m0, k0, d.M, ral, tid, 2);
+                else load_bf<BM, true, NT>(d, reinterpret_cast<const unsigned short*>(d.A_lo) + aoff, d.lda, c.m0, k0, d.M, ral, tid);
                 load_bf<BN, false, NT>(d, reinterpret_cast<const unsigned short*>(d.B_lo) + boff, d.ldb, c.n0, k0, d.N, rbl, tid);
+            }
+        } else if (PREC && d.A_il != nullptr) {
+            // interleaved A (gemm.h): the 64-wide K tile at k0 is 128 consecutive array elements at 2 k0; chunk kc of it sits at
+            // (kc / 32) * 64 + kc % 32, its lo part 32 elements further
+            const int64_t a0 = 2 * aoff + (int64_t)c.m0 * (2 * d.lda), b0 = boff + (int64_t)c.n0 * d.ldb;
+            const int64_t ae = (int64_t)(d.M - 1 - c.m0) * (2 * d.lda) + 2 * (int64_t)d.K, be = (int64_t)(d.N - 1 - c.n0) * d.ldb + d.K;
+            const unsigned kc = (unsigned)((tid & 7) << 3);
+            const unsigned va = 2u * ((unsigned)(tid >> 3) * 2u * (unsigned)d.lda + ((kc >> 5) << 6) + (kc & 31u)), vb = 2u * ((unsigned)(tid >> 3) * (unsigned)d.ldb + kc);
+            const unsigned sa = 2u * (NT / 8) * 2u * (unsigned)d.lda, sb = 2u * (NT / 8) * (unsigned)d.ldb;
+            const __amdgpu_buffer_rsrc_t ra = tile_rsrc(reinterpret_cast<const unsigned short*>(d.A_il) + a0, ae);
+            load_buf<BM, NT>(ra, va, 4u * k0, sa, rah);
+            load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B) + b0, be), vb, 2u * k0, sb, rbh);
+            if constexpr (PREC) {
+                load_buf<BM, NT>(ra, va + 64u, 4u * k0, sa, ral);
+                load_buf<BN, NT>(tile_rsrc(reinterpret_cast<const unsigned short*>(d.B_lo) + b0, be), vb, 2u * k0, sb, rbl);
             }
         } else {
             const int64_t a0 = aoff + (int64_t)c.m0 * d.lda, b0 = boff + (int64_t)c.n0 * d.ldb;
@@ -656,18 +675,26 @@ struct GemmProf {
 static GemmProf g_prof;
 
 paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
-    if (!d.A || !d.B || (!d.C && !d.Cb)) PAA_FAIL(PAA_ERR_ARG, "gemm: null operand");
+    if ((!d.A && !d.A_il) || !d.B || (!d.C && !d.Cb && !d.Cb_il)) PAA_FAIL(PAA_ERR_ARG, "gemm: null operand");
+    if (d.A_il) {
+        if (!d.precision || !d.operand_bf16 || d.a_kseg > 0 || d.a_window || (d.lda & 31) || (d.K & 31) || (d.a_s1 & 31) || (d.a_s2 & 31) || ((uintptr_t)d.A_il & 15))
+            PAA_FAIL(PAA_ERR_ARG, "gemm: A_il needs split precision, plain K-contiguous bf16 rows and lda / K / batch strides that are multiples of 32");
+    }
+    if (d.Cb_il) {
+        if (!d.precision || d.Cb || d.Cb_lo || (d.ldc & 31) || (d.c_s1 & 31) || (d.c_s2 & 31) || ((uintptr_t)d.Cb_il & 15))
+            PAA_FAIL(PAA_ERR_ARG, "gemm: Cb_il needs split precision, no Cb / Cb_lo, and ldc / batch strides that are multiples of 32");
+    }
     if (d.accumulate && !d.C) PAA_FAIL(PAA_ERR_ARG, "gemm: accumulate needs the f32 result");
     if (d.Cb_lo && !d.Cb) PAA_FAIL(PAA_ERR_ARG, "gemm: Cb_lo without Cb");
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.batch <= 0 || d.batch2 <= 0) PAA_FAIL(PAA_ERR_SIZE, "gemm: bad dims %d %d %d", d.M, d.N, d.K);
     const int al = d.operand_bf16 ? 7 : 3;     // elements per 16-byte vector - 1
-    if ((d.lda & al) || (d.ldb & al) || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15))
+    if ((d.lda & al) || (d.ldb & al) || (!d.A_il && ((uintptr_t)d.A & 15)) || ((uintptr_t)d.B & 15))
         PAA_FAIL(PAA_ERR_ARG, "gemm: operands must be 16-byte aligned with leading dimensions that are multiples of %d", al + 1);
     if ((d.a_s1 & al) || (d.a_s2 & al) || (d.b_s1 & al) || (d.b_s2 & al)) PAA_FAIL(PAA_ERR_ARG, "gemm: batch strides must be multiples of %d", al + 1);
     if (d.a_kseg > 0 && ((d.a_kseg & al) || (d.a_kseg_stride & al) || !d.a_kcontig)) PAA_FAIL(PAA_ERR_ARG, "gemm: bad K segmentation");
     if (d.operand_bf16) {
         if (!d.a_kcontig || !d.b_kcontig || (d.K & 7)) PAA_FAIL(PAA_ERR_ARG, "gemm: bf16 operands must be K-contiguous with K %% 8 == 0 (K=%d)", d.K);
-        if (d.precision && (!d.A_lo || !d.B_lo || ((uintptr_t)d.A_lo & 15) || ((uintptr_t)d.B_lo & 15)))
+        if (d.precision && ((!d.A_il && (!d.A_lo || ((uintptr_t)d.A_lo & 15))) || !d.B_lo || ((uintptr_t)d.B_lo & 15)))
             PAA_FAIL(PAA_ERR_ARG, "gemm: split precision needs aligned lo planes");
     }
     if (d.a_window && d.a_kseg <= 0) PAA_FAIL(PAA_ERR_ARG, "gemm: a_window needs a_kseg");
@@ -681,7 +708,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     // vector epilogue: every result / aux / residual row must split into aligned 8-column groups
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool vec = d.operand_bf16 && !narrow && (d.N & 7) == 0 && (d.ldc & 7) == 0 && (d.c_s1 & 7) == 0 && (d.c_s2 & 7) == 0 &&
-                     al16(d.C) && al16(d.C_pre) && al16(d.Cb) && al16(d.Cb_lo) &&
+                     al16(d.C) && al16(d.C_pre) && al16(d.Cb) && al16(d.Cb_lo) && al16(d.Cb_il) &&
                      (!d.aux || (al16(d.aux) && (d.ld_aux & (d.aux_bf16 ? 7 : 3)) == 0 && (d.aux_s1 & 7) == 0 && (d.aux_s2 & 7) == 0)) &&
                      (!d.residual || (al16(d.residual) && (d.ld_res & 3) == 0 && (d.res_s1 & 3) == 0 && (d.res_s2 & 3) == 0)) &&
                      (!d.bias || (al16(d.bias) && (d.bias_s2 & 3) == 0)) &&
@@ -727,7 +754,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             const double c256 = (double)r256 * 256.0, c192 = (double)r192 * 192.0 * 2.0 / 0.95, csq = (double)rsq * 512.0 / 1.08;
             ring = 0;
             double best = c256;
-            if (c192 < best) { best = c192; ring = 7; }
+            if (c192 < best && !d.A_il) { best = c192; ring = 7; }       // (the 192 x 128 ring reads planar A planes only)
             if (!no_sq && d.N % 256 == 0 && ring_cfg_ok(20, d) && csq < best) { best = csq; ring = 20; }
             // 192 x 256 ring (22: eight waves, one per CU): M = 16000, N = 768 is 252 tiles on 256 CUs; +3..11 % over
             // ring 7 on the N = 768 / 2304 products
@@ -761,6 +788,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         else
 #endif
         if (ring && !ring_cfg_ok(ring, d)) ring = 0;
+        if (ring && ring < 20 && d.A_il) ring = 0;               // interleaved A: gemm_ring2.hip and the register-staged kernels
     }
     const int ring_bn = ring == 13 ? 128 : ring ? ring_tile_cols(ring) : 0, ring_bm = ring == 13 ? 192 : ring ? ring_tile_rows(ring) : 0;
     g.tiles_m = cdiv(d.M, ring ? ring_bm : tall ? (bm192 ? 192 : 256) : G_BM);
@@ -778,6 +806,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             if (d.a_window) by = (double)d.a_rows_valid * d.a_kseg * es + (double)d.N * d.K * es;
             if (d.C) by += mn * 4.0 * (d.accumulate ? 2 : 1);
             if (d.Cb) by += mn * 2.0 * (d.Cb_lo ? 2 : 1);
+            if (d.Cb_il) by += mn * 4.0;
             if (d.C_pre) by += mn * (d.aux_bf16 ? 2.0 : 4.0);
             if (d.aux) by += mn * (d.aux_bf16 ? 2.0 : 4.0);
             if (d.residual) by += mn * 4.0;

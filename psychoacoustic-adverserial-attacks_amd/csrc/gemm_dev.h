@@ -53,6 +53,8 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
     unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + coff : nullptr;
     unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + coff : nullptr;
     unsigned short* __restrict__ Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + coff : nullptr;
+    // interleaved bf16 result (gemm.h, Cb_il): element (m, n) at 2 * batch offset + m * 2 ldc + (n / 32) * 64 + n % 32, lo 32 further
+    unsigned short* __restrict__ Cil = d.Cb_il ? reinterpret_cast<unsigned short*>(d.Cb_il) + 2 * (z1 * d.c_s1 + z2 * d.c_s2) : nullptr;
     const int64_t xoff = z1 * d.aux_s1 + z2 * d.aux_s2 + (int64_t)mw * d.ld_aux + nw;
     const float* __restrict__ aux = (d.aux && !x16) ? d.aux + xoff : nullptr;
     const unsigned short* __restrict__ aux16 = (d.aux && x16) ? reinterpret_cast<const unsigned short*>(d.aux) + xoff : nullptr;
@@ -119,6 +121,13 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
                     Cbi[ci] = h;
                     if (Cbli) Cbli[ci] = bf16_bits(v - bf16_to_f32(h));
                 }
+                if (Cil) {
+                    const int n = nw + dn;
+                    const int64_t o = (int64_t)(mw + i * 32 + dm) * (2 * d.ldc) + ((n >> 5) << 6) + (n & 31);
+                    const unsigned short h = bf16_bits(v);
+                    Cil[o] = h;
+                    Cil[o + 32] = bf16_bits(v - bf16_to_f32(h));
+                }
             }
         }
     }
@@ -170,12 +179,18 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
     unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + cbase : nullptr;
     unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + cbase : nullptr;
     unsigned short* __restrict__ Cbl = d.Cb_lo ? reinterpret_cast<unsigned short*>(d.Cb_lo) + cbase : nullptr;
+    // interleaved result planes (gemm.h, Cb_il): this lane's 8 columns sit inside one 32-column group, so the hi and the lo vector of
+    // a row are two 16-byte stores 64 bytes apart; Cb then points at the array and Cbl at the same array + 32 elements
+    const bool cil = d.Cb_il != nullptr;
+    if (cil) { Cb = reinterpret_cast<unsigned short*>(d.Cb_il) + 2 * cbase; Cbl = Cb + 32; }
     const bool ex16 = gg && x16;                        // the extra stream is bf16: 8 columns = one 16-byte vector
     const float* __restrict__ ex = gg ? (ex16 ? nullptr : d.aux + z1 * d.aux_s1 + z2 * d.aux_s2)
                                       : (d.residual ? d.residual + z1 * d.res_s1 + z2 * d.res_s2 : nullptr);
     const unsigned short* __restrict__ exh = ex16 ? reinterpret_cast<const unsigned short*>(d.aux) + z1 * d.aux_s1 + z2 * d.aux_s2 : nullptr;
     const unsigned ldc = (unsigned)d.ldc, ldx = (unsigned)(gg ? d.ld_aux : d.ld_res);
     const unsigned co = (unsigned)row0 * ldc + (unsigned)col;
+    const unsigned cob = cil ? (unsigned)row0 * 2u * ldc + (((unsigned)col >> 5) << 6) + ((unsigned)col & 31u) : co;      // bf16 result offset
+    const unsigned ldcb = cil ? 2u * ldc : ldc;
     const unsigned xo = (unsigned)row0 * ldx + (unsigned)col;
     float bv[8];
 #pragma unroll
@@ -294,8 +309,9 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
         }
         if (Cp16 && live && act == PAA_ACT_GELU) *reinterpret_cast<uint4*>(Cp16 + ci) = make_uint4(pp[0], pp[1], pp[2], pp[3]);
         if (Cb && live) {
-            *reinterpret_cast<uint4*>(Cb + ci) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-            if (Cbl) *reinterpret_cast<uint4*>(Cbl + ci) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+            const unsigned cb = cob + (unsigned)dm * ldcb;
+            *reinterpret_cast<uint4*>(Cb + cb) = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+            if (Cbl) *reinterpret_cast<uint4*>(Cbl + cb) = make_uint4(lp[0], lp[1], lp[2], lp[3]);
         }
     }
 }

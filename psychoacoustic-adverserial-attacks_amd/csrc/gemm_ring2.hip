@@ -44,7 +44,10 @@ __device__ __forceinline__ void wait_vmcnt2() { asm volatile("s_waitcnt vmcnt(%0
 
 // BIL (split mode): the B operand comes from paa_gemm_desc.B_il — hi and lo planes interleaved per 32-element K group — so a K slab
 // of a weight row is ONE 128-byte line; its slot has 128-byte rows (chunks 0-3 hi, 4-7 lo) with the XOR swizzle of the bf16 kernels.
-template <int BM, int BN, int BK, int PREC, int WR, int WC, bool BIL = false>
+// AIL (split mode only): likewise the A operand from paa_gemm_desc.A_il — the activations' planes interleaved per 32-element K group by
+// their producer (Cb_il of the GEMM epilogues, Bf::il of the element-wise kernels) — so that a K slab of an A row, the operand that
+// streams from HBM, is one 128-byte line too; its slots take the same 128-byte-row layout.
+template <int BM, int BN, int BK, int PREC, int WR, int WC, bool BIL = false, bool AIL = false>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int NW = WR * WC;
     constexpr int NPL = PREC ? 2 : 1;
@@ -55,8 +58,10 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int NSTA = 3, NSTB = 2;
     static_assert(!BIL || (PREC == 1 && BK == 32), "interleaved planes: split mode, one 32-element K group per slab");
     constexpr int RBB = BIL ? 128 : RB, CPRB = RBB / 16, RPIB = 1024 / RBB, RBRB = 256 / RBB;      // the B slot's row geometry
+    static_assert(!AIL || (PREC == 1 && BK == 32 && BM % (8 * WR * WC) == 0), "interleaved A planes: split mode, one 32-element K group per slab");
+    constexpr int RBA = AIL ? 128 : RB, CPRA = RBA / 16, RPIA = 1024 / RBA, RBRA = 256 / RBA;      // the A slot's row geometry
     constexpr int ASZ = NPL * BM * RB, BSZ = NPL * BN * RB;        // one slot of each ring: hi rows [| lo rows]  (BIL: BN rows of 128 bytes)
-    constexpr int GA = NPL * BM / RPI / NW, GB = BSZ / 1024 / NW;   // DMA wave-instructions per wave per slab
+    constexpr int GA = ASZ / 1024 / NW, GB = BSZ / 1024 / NW;       // DMA wave-instructions per wave per slab
     constexpr int MI = BM / WR / 32, NJ = BN / WC / 32, KS = BK / 16;
     // split mode only: the last MFMA group of a K slab runs AFTER the certifying barrier, over the reads of the next slab's first
     // fragments (+0..4 % per product; in bf16 mode a group is two MFMAs — too short to cover an LDS round trip — and the form
@@ -119,11 +124,17 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         const int64_t aoff = c.z1 * d.a_s1 + c.z2 * d.a_s2;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-            const int r = (i * NW + wave) * RPI + lane / CPR;             // row of the slot: hi rows, then lo rows
-            const int pl = r / BM, rr = r - pl * BM;
-            const int ch = (lane % CPR) ^ ((rr / RBR) & (CPR - 1));       // global chunk that lands in slot lane % CPR
-            const unsigned short* A = reinterpret_cast<const unsigned short*>(pl ? d.A_lo : (const void*)d.A) + aoff;
-            srcA[i] = A + (int64_t)min(c.m0 + rr, d.M - 1) * d.lda + ch * 8;
+            if constexpr (AIL) {
+                const int rr = (i * NW + wave) * RPIA + lane / CPRA;      // row of the slot (128-byte rows: chunks 0-3 hi, 4-7 lo)
+                const int ch = (lane % CPRA) ^ ((rr / RBRA) & (CPRA - 1));
+                srcA[i] = reinterpret_cast<const unsigned short*>(d.A_il) + 2 * aoff + (int64_t)min(c.m0 + rr, d.M - 1) * (2 * d.lda) + ch * 8;
+            } else {
+                const int r = (i * NW + wave) * RPI + lane / CPR;         // row of the slot: hi rows, then lo rows
+                const int pl = r / BM, rr = r - pl * BM;
+                const int ch = (lane % CPR) ^ ((rr / RBR) & (CPR - 1));   // global chunk that lands in slot lane % CPR
+                const unsigned short* A = reinterpret_cast<const unsigned short*>(pl ? d.A_lo : (const void*)d.A) + aoff;
+                srcA[i] = A + (int64_t)min(c.m0 + rr, d.M - 1) * d.lda + ch * 8;
+            }
         }
     };
     auto set_srcB = [&](int t) {
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         unsigned char* st = smA + ca.slot * ASZ;
 #pragma unroll
         for (int i = 0; i < GA; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcA[i] + (int64_t)ca.slab * BK), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcA[i] + (int64_t)ca.slab * (AIL ? 2 * BK : BK)), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
         if (advance(ca, NSTA) && ca.t < total) set_srcA(ca.t);
         return true;
     };
@@ -175,8 +186,16 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     int offk[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) offk[ks] = ((2 * ks + lh) ^ sw) << 4;
-    const int arow = (wr * (BM / WR) + lr) * RB, brow = (wc * (BN / WC) + lr) * RBB;
+    const int arow = (wr * (BM / WR) + lr) * RBA, brow = (wc * (BN / WC) + lr) * RBB;
     constexpr int ALO = BM * RB, BLO = BN * RB;     // hi -> lo plane distance inside a slot
+    // A fragment offsets of k slice ks: hi / lo plane (AIL: chunks 2 ks + lh and 4 + 2 ks + lh of the 128-byte row)
+    const int swa = (lr / RBRA) & (CPRA - 1);
+    int offah[KS], offal[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        offah[ks] = AIL ? (((2 * ks + lh) ^ swa) << 4) : offk[ks];
+        offal[ks] = AIL ? (((4 + 2 * ks + lh) ^ swa) << 4) : ALO + offk[ks];
+    }
     // B fragment offsets of k slice ks: hi / lo plane (BIL: chunks 2 ks + lh and 4 + 2 ks + lh of the 128-byte row)
     const int swb = (lr / RBRB) & (CPRB - 1);
     int offbh[KS], offbl[KS];
@@ -215,8 +234,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                     bhn[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RBB + offbh[0]);
                     if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * RBB + offbl[0]);
                 }
-                ahn = *reinterpret_cast<const bf16x8*>(sa + offk[0]);
-                if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + ALO + offk[0]);
+                ahn = *reinterpret_cast<const bf16x8*>(sa + offah[0]);
+                if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + offal[0]);
                 __builtin_amdgcn_sched_group_barrier(0x100, (NJ + 1) * NPL, 0);
             }
 #pragma unroll
@@ -229,8 +248,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                 for (int i = 0; i < MI; ++i) {
                     const int ni = (i + 1 < MI) ? i + 1 : 0, nks = (i + 1 < MI) ? ks : ks + 1;
                     if (nks < KS) {
-                        ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 32 * RB + offk[nks < KS ? nks : 0]);
-                        if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + ALO + ni * 32 * RB + offk[nks < KS ? nks : 0]);
+                        ahn = *reinterpret_cast<const bf16x8*>(sa + ni * 32 * RBA + offah[nks < KS ? nks : 0]);
+                        if (PREC) aln = *reinterpret_cast<const bf16x8*>(sa + ni * 32 * RBA + offal[nks < KS ? nks : 0]);
                         if (ni == 0) {
 #pragma unroll
                             for (int j = 0; j < NJ; ++j) {
@@ -254,8 +273,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                             bhn[j] = *reinterpret_cast<const bf16x8*>(sbn + j * 32 * RBB + offbh[0]);
                             if (PREC) bln[j] = *reinterpret_cast<const bf16x8*>(sbn + j * 32 * RBB + offbl[0]);
                         }
-                        ahn = *reinterpret_cast<const bf16x8*>(san + offk[0]);
-                        if (PREC) aln = *reinterpret_cast<const bf16x8*>(san + ALO + offk[0]);
+                        ahn = *reinterpret_cast<const bf16x8*>(san + offah[0]);
+                        if (PREC) aln = *reinterpret_cast<const bf16x8*>(san + offal[0]);
                         have_first = true;
                     }
                     __builtin_amdgcn_s_setprio(1);
@@ -295,20 +314,26 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int PREC, int WR, int WC, bool BIL>
+template <int BM, int BN, int BK, int PREC, int WR, int WC, bool BIL, bool AIL>
 void launch_ring2_il(const GemmArgs& g, hipStream_t st) {
-    static const int per_cu = blocks_per_cu(k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL>, WR * WC * 64);
+    static const int per_cu = blocks_per_cu(k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL, AIL>, WR * WC * 64);
     const int resident = per_cu * device_cus();
     const int total = g.tiles_m * g.tiles_n * g.d.batch;
     const int blocks = resident > 0 ? std::min(total, resident) : total;
-    hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
+    hipLaunchKernelGGL((k_gemm_ring2<BM, BN, BK, PREC, WR, WC, BIL, AIL>), dim3(blocks), dim3(WR * WC * 64), 0, st, g);
 }
 template <int BM, int BN, int BK, int PREC, int WR, int WC>
 void launch_ring2(const GemmArgs& g, hipStream_t st) {
     if constexpr (PREC == 1) {
-        if (g.d.B_il && g.d.b_s1 == 0 && g.d.b_s2 == 0 && !gemm_env_no_bil()) { launch_ring2_il<BM, BN, BK, PREC, WR, WC, true>(g, st); return; }
+        const bool bil = g.d.B_il && g.d.b_s1 == 0 && g.d.b_s2 == 0 && !gemm_env_no_bil();
+        if (g.d.A_il) {         // interleaved activations (gemm.h, A_il)
+            if (bil) launch_ring2_il<BM, BN, BK, PREC, WR, WC, true, true>(g, st);
+            else launch_ring2_il<BM, BN, BK, PREC, WR, WC, false, true>(g, st);
+            return;
+        }
+        if (bil) { launch_ring2_il<BM, BN, BK, PREC, WR, WC, true, false>(g, st); return; }
     }
-    launch_ring2_il<BM, BN, BK, PREC, WR, WC, false>(g, st);
+    launch_ring2_il<BM, BN, BK, PREC, WR, WC, false, false>(g, st);
 }
 
 }  // namespace

@@ -34,11 +34,17 @@ struct CBf {                       // read-only bf16 planes
     const unsigned short* hi = nullptr;
     const unsigned short* lo = nullptr;
     const unsigned short* il = nullptr;      // weights, fp32-parity mode: the two planes interleaved per 32-element K group (gemm.h, B_il)
-    CBf off(int64_t e) const { return CBf{hi + e, lo ? lo + e : nullptr, nullptr}; }
+    bool ail = false;                        // activations: `hi` IS an interleaved array (paa_common.h Bf::il; gemm.h, A_il), `lo` unused
+    CBf off(int64_t e) const { return ail ? CBf{hi + 2 * e, nullptr, nullptr, true} : CBf{hi + e, lo ? lo + e : nullptr, nullptr, false}; }
 };
-static inline CBf ro(const Bf& b) { return CBf{b.hi, b.lo, nullptr}; }
-static inline Bf boff(const Bf& b, int64_t e) { return Bf{b.hi + e, b.lo ? b.lo + e : nullptr}; }
+static inline CBf ro(const Bf& b) { return CBf{b.hi, b.lo, nullptr, b.il}; }
+static inline Bf boff(const Bf& b, int64_t e) { return b.il ? Bf{b.hi + 2 * e, nullptr, true} : Bf{b.hi + e, b.lo ? b.lo + e : nullptr, false}; }
 static const Bf NOBF{nullptr, nullptr};
+// bf16 result planes of a product: planar (Cb, Cb_lo) or one interleaved array (Cb_il)
+static inline void set_cb(paa_gemm_desc& d, const Bf& b) {
+    if (b.il) { d.Cb = nullptr; d.Cb_lo = nullptr; d.Cb_il = b.hi; }
+    else { d.Cb = b.hi; d.Cb_lo = b.lo; d.Cb_il = nullptr; }
+}
 
 struct ConvL {
     int cin, cout, k, s, T, P;
@@ -103,6 +109,9 @@ struct paa_model {
     paa_arch a;
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
+    bool ail;                        // fp32-parity mode: the activation planes that only GEMMs read (conv stack outputs and gradients, the
+                                     // LayerNorm outputs that feed QKV / FFN products, the FFN hidden activation and its gradient) are kept
+                                     // interleaved per 32-element group (paa_common.h Bf::il; gemm.h A_il / Cb_il)
     bool fused;                      // flash-style attention kernels (head_dim 64); else materialised scores
     bool gate;                       // see pre16; false only in -DPAA_EXPERIMENTS builds under PAA_NO_GATE32=1 (fp32-parity A/B)
     bool pre16;                      // What a GELU keeps for its backward pass (L{l}.fpre, and conv{i}.pre, i < last, of the
@@ -124,6 +133,7 @@ struct paa_model {
     Bf c0_w1H{nullptr, nullptr};
     float* gF[2];                    // f32 conv-stack gradients (conv0's input; every layer under the layer-norm variant)
     Bf gH[2];                        // bf16 conv-stack gradients (dgrad GEMM operands), with zero guard rows in front
+    Bf g0H{nullptr, nullptr};        // the gradient wrt conv0's output (planar: k_conv0_dgrad / k_conv0_gn<2> read it); gH[0] when !ail
     float* gz;
     Bf fnH, h0H, xaH, xbH, ctxH, factH, xfinalH;
     float *fp_stats, *h0, *pos_pre, *hsum, *enc_stats, *xa, *xb, *final_in;
@@ -177,6 +187,11 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     m->gate = true;
 #ifdef PAA_EXPERIMENTS      // tools/gate_ab.py: raw pre-activations in fp32-parity mode
     { const char* e = getenv("PAA_NO_GATE32"); m->gate = m->pre16 || !(e && e[0] == '1'); }
+#endif
+    m->ail = m->prec == 1 && a.hidden % 32 == 0 && a.ffn % 32 == 0;
+    for (int i = 0; i < a.n_conv; ++i) m->ail = m->ail && a.conv_dim[i] % 32 == 0;
+#ifdef PAA_EXPERIMENTS      // tools/ail_ab.py: planar activation planes everywhere
+    { const char* e = getenv("PAA_NO_AIL"); if (e && e[0] == '1') m->ail = false; }
 #endif
     for (int i = 0; i < n_tensors; ++i) m->tensors[tensors[i].name] = {tensors[i].d_ptr, tensors[i].numel};
 
@@ -254,10 +269,13 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
             off += n;
             return p;
         };
-        auto take_bf = [&](int64_t n) -> Bf {     // n bf16 elements per plane
-            Bf b;
-            b.hi = reinterpret_cast<unsigned short*>(take((n + 1) / 2));
-            b.lo = m->prec ? reinterpret_cast<unsigned short*>(take((n + 1) / 2)) : nullptr;
+        auto take_bf = [&](int64_t n, bool il = false) -> Bf {     // n bf16 elements per plane; split mode: the two planes are contiguous
+            Bf b;                                                    // (hi, then lo), so the same 2 n elements can hold the interleaved form
+            n = (n + 127) / 128 * 128;
+            b.hi = reinterpret_cast<unsigned short*>(take(m->prec ? n : n / 2));
+            b.lo = m->prec ? b.hi + n : nullptr;
+            b.il = il && m->prec;
+            if (b.il) b.lo = nullptr;
             return b;
         };
         const int64_t GUARD = 8;             // zero rows before / after a row-matrix (dgrad look-back, im2col look-ahead)
@@ -269,7 +287,7 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
             c.gate = m->gate && !a.feat_norm_layer && i < nc - 1;
             c.pre16 = m->pre16 && c.gate;
             c.pre = take(c.pre16 ? (n + 1) / 2 : n);
-            if (i < nc - 1) c.actb = take_bf(n); else c.act_f = take(n);
+            if (i < nc - 1) c.actb = take_bf(n, m->ail); else c.act_f = take(n);
             if (a.feat_norm_layer) { if (i) c.cv = take(n); c.row_stats = take((int64_t)B * c.P * 2); }
         }
         const ConvL& c0 = m->conv[0];
@@ -284,15 +302,17 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         for (int j = 0; j < 2; ++j) {
             float* p = a.feat_norm_layer ? take(gsz) : nullptr;
             m->gF[j] = (pass && p) ? p + GUARD * maxC : nullptr;
-            Bf h = take_bf(gsz);
+            Bf h = take_bf(gsz, m->ail);
             m->gH[j] = pass ? boff(h, GUARD * maxC) : NOBF;
         }
+        if (m->ail && !a.feat_norm_layer) { Bf h = take_bf(gsz); m->g0H = pass ? boff(h, GUARD * maxC) : NOBF; }
+        else m->g0H = m->gH[0];
         const int64_t MH = (int64_t)m->M * H, MF = (int64_t)m->M * F, MC = (int64_t)m->M * C6;
         m->gz = take(MC);
         m->fnH = take_bf(MC); m->fp_stats = take((int64_t)m->M * 2);
         m->h0 = take(MH); m->h0H = take_bf(MH); m->pos_pre = take(MH); m->hsum = take(MH); m->enc_stats = take((int64_t)m->M * 2);
-        m->xa = take(MH); m->xaH = take_bf(MH); m->xb = take(MH); m->xbH = take_bf(MH);
-        m->ctxH = take_bf(MH); m->factH = take_bf(MF); m->xfinalH = take_bf(MH); m->final_in = take(MH);
+        m->xa = take(MH); m->xaH = take_bf(MH, m->ail); m->xb = take(MH); m->xbH = take_bf(MH, m->ail);
+        m->ctxH = take_bf(MH); m->factH = take_bf(MF, m->ail); m->xfinalH = take_bf(MH); m->final_in = take(MH);
         const int64_t PM = (int64_t)B * nh * m->Tp * m->Tp;
         const int64_t LS = (int64_t)B * nh * m->Tp;
         for (int l = 0; l < a.layers; ++l) {
@@ -306,11 +326,11 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         m->nll = take(B);
         m->S_cap = std::min(2047, std::max(64, m->T));    // labels longer than T_e are infeasible (infinite CTC loss) but legal
         m->ctc_work = take((int64_t)B * ctc_work_floats_per_clip(m->T, V, m->S_cap));
-        m->dxa = take(MH); m->dxaH = take_bf(MH); m->dxb = take(MH); m->dxbH = take_bf(MH);
+        m->dxa = take(MH); m->dxaH = take_bf(MH, m->ail); m->dxb = take(MH); m->dxbH = take_bf(MH, m->ail);
         m->dqkvH = take_bf(3 * MH);
         if (m->fused) { m->dctxH = take_bf(MH); m->delta = take(LS); }
         else { m->dctx = take(MH); m->dP = take(PM); }
-        m->dfpreH = take_bf(MF); m->dposH = take_bf(MH); m->dh0 = take(MH); m->dh0H = take_bf(MH); m->dfn = take(MC);
+        m->dfpreH = take_bf(MF, m->ail); m->dposH = take_bf(MH); m->dh0 = take(MH); m->dh0H = take_bf(MH); m->dfn = take(MC);
         if (!pass) {
             m->arena_floats = off;
             hipError_t e = hipMalloc(&m->arena, sizeof(float) * off);
@@ -344,8 +364,9 @@ static paa_gemm_desc gdb(const paa_model* m, CBf A, CBf W, float* C, Bf Cb, int 
                          int64_t ldc) {
     paa_gemm_desc d{};
     d.operand_bf16 = 1;
-    d.A = reinterpret_cast<const float*>(A.hi); d.A_lo = A.lo; d.B = reinterpret_cast<const float*>(W.hi); d.B_lo = W.lo; d.B_il = W.il;
-    d.C = C; d.Cb = Cb.hi; d.Cb_lo = Cb.lo;
+    d.A = reinterpret_cast<const float*>(A.hi); d.A_lo = A.ail ? A.hi : A.lo; d.A_il = A.ail ? A.hi : nullptr;
+    d.B = reinterpret_cast<const float*>(W.hi); d.B_lo = W.lo; d.B_il = W.il;
+    d.C = C; set_cb(d, Cb);
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
     d.a_kcontig = 1; d.b_kcontig = 1; d.batch = 1; d.batch2 = 1; d.alpha = 1.f; d.precision = m->prec;
     return d;
@@ -390,7 +411,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
                                   last ? c.act_f : nullptr, st));
         } else {
             d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.aux_gate = c.gate ? 1 : 0; d.act = PAA_ACT_GELU;
-            if (last) d.C = c.act_f; else { d.Cb = c.actb.hi; d.Cb_lo = c.actb.lo; }
+            if (last) d.C = c.act_f; else set_cb(d, c.actb);
             PAA_TRY(gemm(d, st));
         }
     }
@@ -584,19 +605,24 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
         if (a.feat_norm_layer)                 // through LayerNorm_i to the raw conv output (f32 in, bf16 planes out)
             PAA_TRY(layernorm_bwd(m->gF[ji], c.cv, c.g, c.row_stats, nullptr, nullptr, nullptr, m->gH[ji], B * c.P, c.cout, st));
         const bool out_f32 = a.feat_norm_layer != 0;          // next consumer is an element-wise (LayerNorm backward) kernel
+        const Bf& gout = i == 1 ? m->g0H : m->gH[jo];         // conv0's kernels read planar planes; the dgrad GEMMs further up interleaved ones
         for (int rho = 0; rho < c.s; ++rho) {
             const int Q = c.wdQ[rho];
             const int64_t ldo = (int64_t)c.s * c.cin;
             if (Q < 0) {   // no tap reaches this residue class: zero gradient rows
                 if (out_f32) PAA_HIP(hipMemset2DAsync(m->gF[jo] + (int64_t)rho * c.cin, ldo * 4, 0, (size_t)c.cin * 4, (size_t)B * c.P, st));
-                else PAA_HIP(hipMemset2DAsync(m->gH[jo].hi + (int64_t)rho * c.cin, ldo * 2, 0, (size_t)c.cin * 2, (size_t)B * c.P, st));
+                else if (gout.il) PAA_HIP(hipMemset2DAsync(gout.hi + 2 * (int64_t)rho * c.cin, ldo * 4, 0, (size_t)c.cin * 4, (size_t)B * c.P, st));
+                else {
+                    PAA_HIP(hipMemset2DAsync(gout.hi + (int64_t)rho * c.cin, ldo * 2, 0, (size_t)c.cin * 2, (size_t)B * c.P, st));
+                    if (gout.lo) PAA_HIP(hipMemset2DAsync(gout.lo + (int64_t)rho * c.cin, ldo * 2, 0, (size_t)c.cin * 2, (size_t)B * c.P, st));
+                }
                 continue;
             }
             const int K = (Q + 1) * c.cout;
             paa_gemm_desc d = gdb(m, ro(m->gH[ji]).off(-(int64_t)Q * c.cout), c.wd[rho], nullptr, NOBF, B * c.P, c.cin, K, c.cout, K, ldo);
             d.k_group = kgroup_on() ? c.cout : 0;
             if (out_f32) d.C = m->gF[jo] + (int64_t)rho * c.cin;
-            else { Bf o = boff(m->gH[jo], (int64_t)rho * c.cin); d.Cb = o.hi; d.Cb_lo = o.lo; }
+            else set_cb(d, boff(gout, (int64_t)rho * c.cin));
             d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_gate = pr.gate ? 1 : 0;
             d.aux = pr.pre16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(pr.pre) + (int64_t)rho * c.cin)
                              : pr.pre + (int64_t)rho * c.cin;
@@ -609,7 +635,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
         ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
         ca.k = c.k; ca.stride = c.s; ca.w = c.w0; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
         ca.gn_stats = m->gn_stats; ca.gn_bsums = m->gn_bsums; ca.row_stats = c.row_stats; ca.dpre = m->gF[0]; ca.G = m->G;
-        ca.dpreb = m->gH[0]; ca.G1 = m->G1; ca.w1b = m->c0_w1H; ca.Mx = m->c0_Mx; ca.kc = m->c0_kc;
+        ca.dpreb = m->g0H; ca.G1 = m->G1; ca.w1b = m->c0_w1H; ca.Mx = m->c0_Mx; ca.kc = m->c0_kc;
         PAA_TRY(conv0_backward(ca, a.feat_norm_layer, m->prec, m->c0_part, grad, st));
     }
     return PAA_OK;
@@ -720,7 +746,7 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
         else if (n == "dlogits") { p = m->dlogits; cnt = M * V; }
         else if (n == "nll") { p = m->nll; cnt = B; }
         else if (n == "G" && m->G) { p = m->G; cnt = (int64_t)B * c0.P * c0.k; }
-        else if (n == "gbuf0") { if (m->gF[0]) p = m->gF[0]; else pb = m->gH[0]; cnt = (int64_t)B * c0.P * c0.cout; }
+        else if (n == "gbuf0") { if (m->gF[0]) p = m->gF[0]; else pb = m->g0H; cnt = (int64_t)B * c0.P * c0.cout; }
         else if (n == "dh0") { p = m->dh0; cnt = M * H; }
         else if (n == "dfn") { p = m->dfn; cnt = M * a.conv_dim[nc - 1]; }
         else if (n == "dxa") { p = m->dxa; cnt = M * H; }
@@ -733,6 +759,19 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
         if (p) {
             if (hipMemcpy(host, p, sizeof(float) * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         } else {
+            if (pb.il) {      // interleaved planes (paa_common.h Bf::il): element i at il_index(i), its lo part 32 further
+                const int64_t n2 = ((nn + 31) / 32) * 64;
+                std::vector<unsigned short> both(n2);
+                if (hipMemcpy(both.data(), pb.hi, 2 * n2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                for (int64_t i = 0; i < nn; ++i) {
+                    const size_t j = il_index((size_t)i);
+                    uint32_t u = (uint32_t)both[j] << 16, u2 = (uint32_t)both[j + 32] << 16;
+                    float v, v2;
+                    memcpy(&v, &u, 4); memcpy(&v2, &u2, 4);
+                    host[i] = v + v2;
+                }
+                return cnt;
+            }
             std::vector<unsigned short> hi(nn), lo(pb.lo ? nn : 0);
             if (hipMemcpy(hi.data(), pb.hi, 2 * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;
             if (pb.lo && hipMemcpy(lo.data(), pb.lo, 2 * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -69,10 +69,15 @@ __device__ __forceinline__ T block_sum(T v, T* sm) {
 }
 
 // bf16 planes: hi = bf16(v) and, in split (fp32-parity) mode, lo = bf16(v - hi).  Either pointer may be null.
+// il (split mode only): ONE array of 2 n elements at `hi` holds both planes interleaved per 32-element group,
+// [32 hi | 32 lo | 32 hi | ...] (gemm.h, A_il / Cb_il): element i lives at il_index(i), its lo part 32 further.  Rows of these
+// tensors are multiples of 32 elements, so the map needs no row length.  `lo` is not used then.
 struct Bf {
     unsigned short* hi;
     unsigned short* lo;
+    bool il = false;
 };
+__host__ __device__ __forceinline__ size_t il_index(size_t i) { return ((i >> 5) << 6) + (i & 31); }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 // two values -> one dword of two bf16 (a in the low half): ONE v_cvt_pk_bf16_f32 on gfx950 (round to nearest even, as bf16_bits)
@@ -84,6 +89,12 @@ __device__ __forceinline__ unsigned bf16_pack2(float a, float b) {
 __device__ __forceinline__ void store_bf16(const Bf& o, size_t i, float v) {
     if (o.hi) {
         const unsigned short h = bf16_bits(v);
+        if (o.il) {
+            const size_t j = il_index(i);
+            o.hi[j] = h;
+            o.hi[j + 32] = bf16_bits(v - bf16_to_f32(h));
+            return;
+        }
         o.hi[i] = h;
         if (o.lo) o.lo[i] = bf16_bits(v - bf16_to_f32(h));
     }
@@ -95,12 +106,14 @@ __device__ __forceinline__ void store_bf16x4(const Bf& o, size_t i, const float 
     unsigned h[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) h[j] = bf16_bits(v[j]);
-    *reinterpret_cast<uint2*>(o.hi + i) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    if (o.lo) {
+    unsigned short* ph = o.il ? o.hi + il_index(i) : o.hi + i;
+    unsigned short* pl = o.il ? ph + 32 : (o.lo ? o.lo + i : nullptr);
+    *reinterpret_cast<uint2*>(ph) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    if (pl) {
         unsigned l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) l[j] = bf16_bits(v[j] - __uint_as_float(h[j] << 16));
-        *reinterpret_cast<uint2*>(o.lo + i) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        *reinterpret_cast<uint2*>(pl) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
     }
 }
 

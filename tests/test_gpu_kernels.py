@@ -293,6 +293,75 @@ def test_gemm_interleaved_weight_planes(cfg):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("cfg,case", [(1, "tall"), (20, "tall"), (22, "tall"), (1, "conv"), (20, "conv"), (22, "conv"), (0, "seg_small"), (0, "narrow"), (0, "auto_tall")])
+def test_gemm_interleaved_activation_planes(cfg, case):
+    """paa_gemm_desc.A_il / Cb_il (fp32-parity mode): the activations' hi / lo planes in ONE array interleaved per 32-element group, as
+    operand and as result.  Same products in the same order as the planar form on every kernel that can meet such a tensor — the
+    separate-ring kernels (20 / 22), the register-staged ones (1), the general loader (K % 64 != 0) and the narrow tile — so the
+    de-interleaved results must equal the planar run bit for bit (which test_gemm_bf16_operands / _ring_configurations check
+    against numpy)."""
+    from paa_amd.model import split_bf16
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    shapes = {  # M, N, K, lda, A elements, extra descriptor fields
+        "tall": (2200, 512, 384, 384, 2200 * 384, dict(act=1, aux_gate=1, alpha=0.5)),
+        "auto_tall": (16000, 768, 768, 768, 16000 * 768, dict()),
+        "conv": (4000, 512, 384, 256, (2 * 4000 + 8) * 128, dict(row_period=500, row_valid=499, act=2, k_group=128)),
+        "seg_small": (300, 96, 96, 96, 300 * 96, dict()),
+        "narrow": (1000, 32, 768, 768, 1000 * 768, dict()),
+    }
+    M, N, K, lda, na, extra = shapes[case]
+    A = rng.normal(size=na).astype(np.float32)
+    Bw = rng.normal(size=(N, K)).astype(np.float32)
+    (ah, al), (bh, bl) = split_bf16(A), split_bf16(Bw)
+    ail = np.stack([ah.reshape(-1, 32), al.reshape(-1, 32)], axis=1).reshape(-1)           # [32 hi | 32 lo] per group of the flat buffer
+    t = {k: torch.from_numpy(v.view(np.int16)).cuda() for k, v in dict(ah=ah, al=al, bh=bh, bl=bl, ail=ail).items()}
+    bias = torch.from_numpy(rng.normal(size=N).astype(np.float32)).cuda()
+    aux = torch.from_numpy(rng.normal(size=M * N).astype(np.float32)).cuda()
+    outs = []
+    try:
+        L.paa_gemm_config(cfg)
+        for il in (False, True):
+            d = _lib.PaaGemmDesc()
+            d.A, d.A_lo, d.B, d.B_lo = t["ah"].data_ptr(), t["al"].data_ptr(), t["bh"].data_ptr(), t["bl"].data_ptr()
+            d.A_il = t["ail"].data_ptr() if il else None
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, K, N
+            d.a_kcontig = d.b_kcontig = d.batch = d.batch2 = d.operand_bf16 = d.precision = 1
+            d.alpha, d.bias = 1.0, bias.data_ptr()
+            for k, v in extra.items():
+                setattr(d, k, v)
+            c32 = torch.zeros(M * N, device="cuda")
+            pre = torch.zeros(M * N, device="cuda")
+            planes = torch.zeros(2 * M * N, dtype=torch.int16, device="cuda")
+            d.C = c32.data_ptr()
+            if extra.get("act") == 1:
+                d.C_pre = pre.data_ptr()
+            if extra.get("act") == 2:
+                d.aux, d.ld_aux = aux.data_ptr(), N
+            if il and N % 32 == 0:
+                d.Cb_il = planes.data_ptr()
+            else:
+                d.Cb, d.Cb_lo = planes.data_ptr(), planes.data_ptr() + 2 * M * N
+            _lib.check(L.paa_gemm(C.byref(d), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            pl = planes.cpu().numpy()
+            if il and N % 32 == 0:
+                g = pl.reshape(-1, 2, 32)
+                hi, lo = g[:, 0].reshape(-1), g[:, 1].reshape(-1)
+            else:
+                hi, lo = pl[:M * N], pl[M * N:]
+            outs.append((c32.cpu().numpy().copy(), pre.cpu().numpy().copy(), hi.copy(), lo.copy()))
+    finally:
+        L.paa_gemm_config(0)
+    assert np.abs(outs[0][0]).max() > 0 and np.abs(outs[0][2]).max() > 0
+    for name, a, b in zip(("C", "C_pre", "Cb hi", "Cb lo"), *outs):
+        assert np.array_equal(a, b), (case, cfg, name)
+    # and against a float64 product of the split operands (loose: this is a layout test)
+    if case != "conv" and not extra.get("act"):
+        ref = (A.reshape(M, K).astype(np.float64) @ Bw.T.astype(np.float64)) + bias.cpu().numpy()
+        assert rel_err(outs[1][0].reshape(M, N), ref) < 1e-4
+
+
 def test_layernorm_fwd_bwd():
     torch.manual_seed(0)
     for rows, cols in ((37, 512), (130, 768), (9, 64), (5, 32)):
@@ -399,7 +468,7 @@ def test_ctc_neg_inf_logits():
     torch.cuda.synchronize()
     got = out_nll.cpu()
     print("ctc -inf logits nll", got.tolist(), nll.tolist())
-    assert bool(torch.isfinite(got[:2]).all()) and bool(torch.isinf(got[2])) and float(nll[2]) > 5e3
+    assert bool(torch.isfinite(got[:2]).all()) and bool(torch.isinf(got[2])) and float(nll.detach()[2]) > 5e3
     assert bool(torch.isfinite(dl[:2]).all())
     e1, e2 = rel_err(got[:2], nll.detach()[:2]), rel_err(dl.cpu()[:2], lr.grad[:2])
     print(f"ctc -inf logits: nll {e1:.2e} grad {e2:.2e}")

@@ -92,15 +92,17 @@ def test_load_model_from_local_checkpoint(tmp_path, norm, stable):
                                                   "--optimizer_type", "pgd"])
     m, proc = build.load_model(args, max_batch=B, length=L)
     assert m.arch == a and proc is not None
-    texts = ["hello world it's", "a <unk> b"]
-    lab_proc = loss_helpers.make_labels(texts, proc, args, B)
-    lab_own = loss_helpers.make_labels(texts, None, args, B)
-    assert torch.equal(lab_proc, lab_own)
+    for texts in (["hello world it's", "a <unk> b"], ["ab cd", "hello"]):        # the second pair is CTC-feasible in 24 frames
+        lab_proc = loss_helpers.make_labels(texts, proc, args, B)
+        lab_own = loss_helpers.make_labels(texts, None, args, B)
+        assert torch.equal(lab_proc, lab_own)
     clean = torch.from_numpy(synth.clean_audio(B, L)).cuda()
     p = torch.from_numpy(synth.perturbation(L) * np.float32(1e-2)).cuda()
     got = m.fwd_bwd(clean, p, lab_proc, +1)
-    direct = PaaModel(a, sdn, B, L, "fp32").fwd_bwd(clean, p, lab_own, +1)
+    m2 = PaaModel(a, sdn, B, L, "fp32")
+    direct = m2.fwd_bwd(clean, p, lab_own, +1)
     torch.cuda.synchronize()
+    assert torch.isfinite(got["grad"]).all() and float(got["grad"].abs().max()) > 0
     assert torch.equal(got["logits"], direct["logits"]) and torch.equal(got["grad"], direct["grad"])
     with torch.no_grad():
         ref = hf(input_values=(clean.cpu() + p.cpu()).clamp(-1, 1), labels=lab_own)
