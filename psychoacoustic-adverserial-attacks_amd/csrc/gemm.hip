@@ -489,14 +489,17 @@ __global__ __launch_bounds__(WM * 128, (WM == 4 && PREC == 0) ? 4 : 2) void k_ge
 // 256 output rows instead of 128 (+11 % on the kernel); fragment reads run one k slice ahead of the MFMAs (+3 %).
 // Tried without effect: weight stages requested two ahead through a second register set (spills in split mode), weight
 // rows padded off the 4 KB stride (L2 channel spread).  The kernel sits at ~0.6 PFLOP/s (0.8 counting the 16 padded columns).
-template <int PREC, int KS, int MI>
-__global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
-    constexpr int BM = 128 * MI, TB = 4, NPL = PREC ? 2 : 1;
+// WV waves of 32 MI rows each: the split-mode tile (two planes of slab and weights: 137 KB of LDS) leaves room for ONE workgroup per CU,
+// so it runs as 8 waves of 32 rows (two instruction streams per SIMD) instead of 4 waves of 64 rows.
+template <int PREC, int KS, int MI, int WV = 4>
+__global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void k_gemm_win(GemmArgs g, int taps) {
+    constexpr int NT = WV * 64;
+    constexpr int BM = 32 * MI * WV, TB = 4, NPL = PREC ? 2 : 1;
     constexpr int ALD = KS + 8;                            // slab row stride (bf16)
     constexpr int BLD = TB * KS + 8;                       // weight stage row stride (bf16)
     constexpr int CPR = KS / 8;                            // 16-byte chunks per slab row
     constexpr int BCH = TB * KS / 8;                       // chunks per weight row per stage
-    constexpr int NB = (64 * BCH + 255) / 256;             // weight chunks per thread per stage
+    constexpr int NB = (64 * BCH + NT - 1) / NT;           // weight chunks per thread per stage
     extern __shared__ __attribute__((aligned(16))) unsigned short smw[];
     const paa_gemm_desc& d = g.d;
     const int srows = BM + taps - 1;
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
     const unsigned short* Bp[2] = {reinterpret_cast<const unsigned short*>(d.B) + boff,
                                    PREC ? reinterpret_cast<const unsigned short*>(d.B_lo) + boff : nullptr};
     // slab: global row m0 - pad + sr, zero outside the clip
-    for (int i = tid; i < srows * CPR; i += 256) {
+    for (int i = tid; i < srows * CPR; i += NT) {
         const int sr = i / CPR, ch = i - sr * CPR;
         const int tr = m0 - d.a_pad + sr;
         const bool ok = tr >= 0 && tr < d.a_rows_valid;
@@ -523,12 +526,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
         }
     }
     // weight rows >= N stay zero for the whole kernel
-    for (int i = tid; i < NPL * 64 * BLD / 8; i += 256) reinterpret_cast<uint4*>(sB)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < NPL * 64 * BLD / 8; i += NT) reinterpret_cast<uint4*>(sB)[i] = make_uint4(0u, 0u, 0u, 0u);
     uint4 rb[NPL][NB];
     auto bload = [&](int st) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int i = tid + 256 * u;
+            const int i = tid + NT * u;
             const int n = i / BCH, ch = i - n * BCH;
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_win(GemmArgs g, int taps) {
     auto bstore = [&]() {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int i = tid + 256 * u;
+            const int i = tid + NT * u;
             const int n = i / BCH, ch = i - n * BCH;
             if (i < 64 * BCH && n < d.N) {
 #pragma unroll
@@ -820,22 +823,22 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         const int taps = d.K / d.a_kseg;
         const int npl = d.precision ? 2 : 1;
         // 256-row tiles (64 rows per wave) for wav2vec2-base's 48-channel groups when the clip has more than 128 rows
-        const int mi = (d.a_kseg == 48 && d.M > 128) ? 2 : 1;
+        const int mi = (d.a_kseg == 48 && d.M > 128) ? 2 : 1;          // 256-row tiles: 4 waves of 64 rows (bf16) / 8 waves of 32 rows (split)
         const size_t lds = 2 * (size_t)npl * ((size_t)(128 * mi + taps - 1) * (d.a_kseg + 8) + 64 * (size_t)(4 * d.a_kseg + 8));
         if (lds <= 150 * 1024) {
             dim3 wgrid(cdiv(d.M, 128 * mi), d.batch);
-#define PAA_WIN(P, KS_, MI_)                                                                                                 \
+#define PAA_WIN(P, KS_, MI_, WV_)                                                                                            \
             {                                                                                                                \
                 static bool attr = false;                                                                                    \
-                if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<P, KS_, MI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
-                hipLaunchKernelGGL((k_gemm_win<P, KS_, MI_>), wgrid, dim3(256), lds, st, g, taps);                           \
+                if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<P, KS_, MI_, WV_>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
+                hipLaunchKernelGGL((k_gemm_win<P, KS_, MI_, WV_>), wgrid, dim3(WV_ * 64), lds, st, g, taps);                 \
             }
             if (prof) { g_prof.variant[g_prof.n] = 40 + (d.precision ? 4 : 0); }
             if (d.a_kseg == 48) {
-                if (mi == 2) { if (d.precision) PAA_WIN(1, 48, 2) else PAA_WIN(0, 48, 2) }
-                else { if (d.precision) PAA_WIN(1, 48, 1) else PAA_WIN(0, 48, 1) }
+                if (mi == 2) { if (d.precision) PAA_WIN(1, 48, 1, 8) else PAA_WIN(0, 48, 2, 4) }
+                else { if (d.precision) PAA_WIN(1, 48, 1, 4) else PAA_WIN(0, 48, 1, 4) }
             }
-            else { if (d.precision) PAA_WIN(1, 64, 1) else PAA_WIN(0, 64, 1) }
+            else { if (d.precision) PAA_WIN(1, 64, 1, 4) else PAA_WIN(0, 64, 1, 4) }
 #undef PAA_WIN
             if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }
             PAA_LAUNCH_CHECK();

@@ -41,9 +41,15 @@ def main(args) -> int:
     spl_thresh = build.init_phon_threshold_tensor(args)
     train_loader, eval_loader, test_loader, audio_len = build.create_data_loaders(args, rank, world)
     model, processor = build.load_model(args, max_batch=int(args.batch_size), length=audio_len)
-    first = train_loader[0][0].to(args.device) if train_loader else None
-    p = build.init_perturbation(args, audio_len, spl_thresh, interp, first)
-    if world > 1:          # the initial projection saw this rank's first shard only: every rank starts from rank 0's p
+    first = train_loader[0][0] if train_loader else None
+    if world > 1 and first is not None:
+        # the initial projection (build.py:301-304) sees the first GLOBAL batch, as the one-process run does: the shards are
+        # gathered once at set-up (sizes may differ by a clip, hence the object collective)
+        shards = [None] * world
+        torch.distributed.all_gather_object(shards, first.cpu())
+        first = torch.cat(shards, dim=0)
+    p = build.init_perturbation(args, audio_len, spl_thresh, interp, first.to(args.device) if first is not None else None)
+    if world > 1:          # identical by construction; the broadcast only guards against a rank-dependent resume file
         torch.distributed.broadcast(p.data, src=0)
     writer = rank == 0
     optimizer, scheduler = (build.create_optimizer(args, p) if args.optimizer_type == "adam" else (None, None))

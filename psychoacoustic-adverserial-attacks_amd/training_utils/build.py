@@ -181,17 +181,18 @@ def _batches(x, texts, batch_size):
     return [(x[i:i + batch_size], texts[i:i + batch_size]) for i in range(0, len(texts), batch_size)]
 
 
-def shard_batches(batches, rank: int, world: int):
+def shard_batches(batches, rank: int, world: int, keep_empty: bool = False):
     """Data-parallel runs: every GLOBAL batch (x (n, L), texts) is cut into ``world`` contiguous shards whose sizes
     differ by at most one clip; rank r keeps shard r.  Ranks may therefore hold different numbers of clips in a step (the
-    packed all-reduce carries the clip count, training_utils/pgd.py); a trailing batch with fewer clips than ranks is
-    dropped, because every rank must run every step."""
+    packed all-reduce carries the clip count, training_utils/pgd.py).  A batch with fewer clips than ranks is dropped from a
+    TRAINING loader (every rank must run every step with at least one clip); an evaluation loader keeps it
+    (``keep_empty``): the ranks past the last clip get an empty shard and contribute zeros to the evaluation's all-reduce."""
     if world <= 1:
         return list(batches)
     out = []
     for x, texts in batches:
         n = len(texts)
-        if n < world:
+        if n < world and not keep_empty:
             continue
         lo = rank * n // world
         hi = (rank + 1) * n // world
@@ -240,7 +241,7 @@ def create_data_loaders(args, rank: int = 0, world: int = 1):
         g = copy.copy(args)
         g.batch_size = int(args.batch_size) * world
         tr, ev, te, length = create_data_loaders(g)
-        return shard_batches(tr, rank, world), shard_batches(ev, rank, world), shard_batches(te, rank, world), length
+        return shard_batches(tr, rank, world), shard_batches(ev, rank, world, True), shard_batches(te, rank, world, True), length
     bs = int(args.batch_size)
     data_dir = getattr(args, "data_dir", None)
     if data_dir:

@@ -126,3 +126,61 @@ def test_bench_starts_its_own_ranks():
                          "--seconds", "0.001", "--arch", "tiny", "--no_cpu_baseline", "--no_fft_bench"],
                         env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode != 0 and "rank" in r2.stderr
+
+
+def _runner_worker(rank, world, port, logs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      PAA_DIST_BACKEND="gloo")
+    from paa_amd import run_attack
+    from paa_amd.training_utils import parser
+    args = parser.create_arg_parser().parse_args(["--arch", "tiny", "--audio_seconds", "0.5", "--batch_size", "2", "--steps_per_epoch", "2",
+                                                  "--num_epochs", "2", "--logs_dir", logs, "--dtype", "fp32", "--silent",
+                                                  "--optimizer_type", "pgd", "--norm_type", "snr", "--snr_db", "40"])
+    rc = run_attack.main(args)
+    q.put((rank, rc, args.save_dir))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_runner_two_ranks_matches_one_rank_on_the_global_batch(tmp_path):
+    """The drop-in runner launched with WORLD_SIZE=2 (as torch.distributed.run does; gloo here, both ranks on the one GPU):
+    global batches of batch_size x 2 clips sharded over the ranks (build.shard_batches), the packed all-reduce inside the step,
+    the epoch-end reduction of the WER counts and the sharded evaluation's all-reduce.  Rank 0 writes the files; they must equal
+    those of ONE rank run with batch_size x 2 — the same global batches — up to the summation order of the shards."""
+    import json
+    from paa_amd import run_attack
+    from paa_amd.training_utils import parser
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    logs2 = str(tmp_path / "dp2")
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, logs2, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert [r[1] for r in res] == [0, 0]
+    d2 = json.load(open(os.path.join(res[0][2], "results.json")))
+    p2 = torch.load(os.path.join(res[0][2], "perturbation.pt"), weights_only=True)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    args = parser.create_arg_parser().parse_args(["--arch", "tiny", "--audio_seconds", "0.5", "--batch_size", "4", "--steps_per_epoch", "2",
+                                                  "--num_epochs", "2", "--logs_dir", str(tmp_path / "dp1"), "--dtype", "fp32", "--silent",
+                                                  "--optimizer_type", "pgd", "--norm_type", "snr", "--snr_db", "40"])
+    assert run_attack.main(args) == 0
+    d1 = json.load(open(os.path.join(args.save_dir, "results.json")))
+    p1 = torch.load(os.path.join(args.save_dir, "perturbation.pt"), weights_only=True)
+    print("DP2 results:", json.dumps(d2))
+    print("one-rank results:", json.dumps(d1))
+    print(open(os.path.join(res[0][2], "train.log")).read()[-1500:])
+    assert d2["finished_training"] == 1.0 and d2["best_epoch"] == d1["best_epoch"]
+    for key in ("final_test_perturbed", "final_test_clean", "best_train_score"):
+        for m_ in ("ctc", "wer"):
+            assert d2[key][m_] == pytest.approx(d1[key][m_], rel=2e-3, abs=1e-6), (key, m_, d2[key], d1[key])
+    diff = (p2 - p1).abs().numpy()
+    scale = float(p1.abs().max())
+    print(f"runner DP2 vs one rank: p max diff {diff.max() / scale:.2e}, fraction differing {(diff > 1e-5 * scale).mean():.2e}")
+    assert (diff > 1e-5 * scale).mean() < 2e-2            # sign flips where a shard-summed gradient entry is numerically ~0

@@ -176,4 +176,7 @@ def test_shard_batches_and_objective():
             assert torch.equal(xs, batches[step][0]) and ts == batches[step][1]
             sizes = [len(s[step][1]) for s in shards]
             assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
-    assert len(build.shard_batches(batches, 0, 3)) == 1            # the 2-clip batch cannot feed 3 ranks
+    assert len(build.shard_batches(batches, 0, 3)) == 1            # the 2-clip batch cannot feed 3 ranks in training
+    ev = [build.shard_batches(batches, r, 3, keep_empty=True) for r in range(3)]
+    assert [len(e) for e in ev] == [2, 2, 2] and sorted(len(e[1][1]) for e in ev) == [0, 1, 1]
+    assert sum((e[1][1] for e in ev), []) == ["a", "b"]
