@@ -29,6 +29,6 @@ paa_status spec_stft(const SpecArgs& a, int rows, hipStream_t st);     // fourie
 paa_status spec_istft(const SpecArgs& a, int rows, hipStream_t st);    // fourier_transforms.py:31-41
 // per-bin op on a caller-supplied spectrum (projections.py:68-159 called on a (B, F, T) tensor), frame-major storage
 paa_status spec_apply(const SpecArgs& a, int op, int rows, const float* scale, int* n_part, hipStream_t st);
-int spec_groups(int T, int rows);        // workgroups per row spec_project / spec_istft launch (size of the FM partial array / rows)
+int spec_groups(int T, int rows, int op, bool src_spec);        // workgroups per row spec_project / spec_istft launch (size of the FM partial array / rows)
 
 }  // namespace paa

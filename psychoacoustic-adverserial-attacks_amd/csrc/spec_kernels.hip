@@ -261,43 +261,63 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
     return wsum;
 }
 
-// NW frames of one row per workgroup -> NW - 3 output hop-blocks.  grid: (groups, rows).
-template <int OP, bool SRC_SPEC, int NW>
+// NW * FPW frames of one row per workgroup -> NW * FPW - 3 output hop-blocks.  grid: (groups, rows).
+// FPW = 2 (batched shapes, round 3): every wave computes TWO frames, f = wave and f = NW + wave, one after the other — its twiddle /
+// window registers serve both, and the 3-frame halo a workgroup recomputes is 3 of 24 frames instead of 3 of 16.  The first frame's
+// windowed result (1024 floats) is parked in a result area behind the exchange buffers before the second frame reuses the wave's
+// exchange buffer: 12 x (5 + 4) KB = 108 KB of LDS (+ 20 KB for the FM table), one workgroup per CU as before.
+template <int OP, bool SRC_SPEC, int NW, int FPW = 1>
 __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float2 xbuf[];                   // [NW][XB]
-    constexpr int NOUT = NW - 3;
+    extern __shared__ __attribute__((aligned(16))) float2 xbuf[];                   // [NW][XB] exchange | [NW][512] parked first frames (FPW = 2)
+    constexpr int NFR = NW * FPW, NOUT = NFR - 3;
+    constexpr int TAIL = NW * XB + (FPW == 2 ? NW * (N / 2) : 0);                    // float2 slots in front of the small arrays
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x, row = blockIdx.y;
     const int c0 = 2 + g * NOUT;                              // first output hop-block (padded-signal block index)
-    const int t = c0 - 3 + wave;                              // this wave's frame
     float2* xb = xbuf + wave * XB;
+    float* park = reinterpret_cast<float*>(xbuf + NW * XB);   // [NW][1024] (FPW = 2)
     BinCtx c;
     c.fm = a.fm; c.thr = a.thr; c.thr_off = a.phon_ref - (OP == SOP_PHON ? a.thr_max[0] : 0.f);
     c.bin_hz = a.bin_hz; c.min_f = a.min_f; c.max_f = a.max_f;
-    if (OP == SOP_FM && NW == 16) {
+    if (OP == SOP_FM && NFR >= 16) {
         // batched shape: the 10 x 513 weight table goes to LDS once per workgroup: the per-bin lookups (row chosen by the bin's own level)
         // were three dependent global loads per bin on the frame's critical path
-        float* fml = reinterpret_cast<float*>(xbuf + NW * XB) + 64;
+        float* fml = reinterpret_cast<float*>(xbuf + TAIL) + 64;
         for (int i = tid; i < 10 * F; i += NW * 64) fml[i] = a.fm[i];
         c.fm = fml;
         __syncthreads();
     }
     float wsum = 0.f;
-    if (t >= 0 && t < a.T) {
+    {
         LaneTw tw;
-        lane_tw(tw, a.tw, a.win, lane);
-        wsum = wave_frame<OP, SRC_SPEC, false>(a, c, tw, xb, row, t, lane);
-        if (!(wave >= 3 || g == 0)) wsum = 0.f;               // halo frames belong to the previous workgroup's sum
-    } else {
+        lane_tw(tw, a.tw, a.win, lane);                       // once per wave: serves both of its frames
+#pragma unroll 1
+        for (int q = 0; q < FPW; ++q) {
+            const int f = q * NW + wave;                      // frame slot inside the workgroup
+            const int t = c0 - 3 + f;                         // frame index of the row
+            if (t >= 0 && t < a.T) {
+                const float ws = wave_frame<OP, SRC_SPEC, false>(a, c, tw, xb, row, t, lane);
+                if (f >= 3 || g == 0) wsum += ws;             // halo frames belong to the previous workgroup's sum
+            } else {
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(0.f, 0.f);
+                for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(0.f, 0.f);
+            }
+            if (FPW == 2 && q == 0) {                         // park the first frame: 1024 floats, 4 x 16 bytes per lane
+                wave_fence();
+                const float4* src = reinterpret_cast<const float4*>(xb);
+                float4* dst = reinterpret_cast<float4*>(park + wave * N);
+                const float4 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
+                dst[lane] = v0; dst[lane + 64] = v1; dst[lane + 128] = v2; dst[lane + 192] = v3;
+                wave_fence();
+            }
+        }
     }
     double dsum = 0.0;
     if (OP == SOP_FM) dsum = wave_sum((double)wsum);
     __syncthreads();                                          // every frame of the workgroup is in LDS
     if (OP == SOP_FM) {
-        double* red = reinterpret_cast<double*>(xbuf + NW * XB);
+        double* red = reinterpret_cast<double*>(xbuf + TAIL);
         if (lane == 0) red[wave] = dsum;
         __syncthreads();
         if (tid == 0) {
@@ -306,8 +326,12 @@ __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
             a.part[(size_t)row * gridDim.x + g] = s;
         }
     }
-    // overlap-add: block j = c0 + jj <- frames j-3..j = waves jj..jj+3 at offsets 768, 512, 256, 0 (+ r)
+    // overlap-add: block j = c0 + jj <- frames j-3..j = frame slots jj..jj+3 at offsets 768, 512, 256, 0 (+ r)
     const float* fb = reinterpret_cast<const float*>(xbuf);
+    auto frame_ptr = [&](int f) -> const float* {            // windowed samples of frame slot f
+        if (FPW == 2) return f < NW ? park + f * N : fb + (f - NW) * (2 * XB);
+        return fb + f * (2 * XB);
+    };
     const int valid_len = HOP * (a.T - 1);
     float* outr = a.out + (size_t)row * a.out_len;
     for (int i = tid; i < NOUT * HOP; i += NW * 64) {
@@ -320,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
             // interior: all four frames exist and the periodic Hann window's squared overlap-add is exactly 3/2
             // (sum over the four quarter-period shifts of (1/2 - 1/2 cos)^2: the cos and cos 2x terms cancel)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sum += fb[(jj + q) * (2 * XB) + HOP * (3 - q) + r];
+            for (int q = 0; q < 4; ++q) sum += frame_ptr(jj + q)[HOP * (3 - q) + r];
             env = 1.5f;
         } else {
 #pragma unroll
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
                 const int tq = j - 3 + q;
                 if (tq >= 0 && tq < a.T) {
                     const int n = HOP * (3 - q) + r;
-                    sum += fb[(jj + q) * (2 * XB) + n];
+                    sum += frame_ptr(jj + q)[n];
                     const float w = a.win[n];
                     env += w * w;
                 }
@@ -378,51 +402,68 @@ __global__ __launch_bounds__(256) void k_spec_apply(SpecArgs a, int64_t n, const
     }
 }
 
-// Frames per workgroup: 16 (13 / 16 of the FFTs useful, one workgroup per CU) for batches, 8 (5 / 8 useful, two per CU)
-// otherwise.  4 (one hop-block per workgroup) was measured SLOWER at (1, 160000): 10.2 vs 9.1 us — four times the FFTs for
-// no shorter critical path; 12 (9 / 12 useful, two workgroups per CU) was measured slower on the batch: 84 vs 79 us at (32, 160000) —
-// the kernel is bound by its instruction stream, so the extra halo FFTs cost more than the extra waves in flight hide.  Both stay
-// reachable through PAA_SPEC_NW in -DPAA_EXPERIMENTS builds.
-static int spec_nw(int T, int rows) {
+// Frames per workgroup.  Single rows / small batches: 8 waves x 1 frame (5 / 8 of the FFTs useful, two workgroups per CU).  Batches
+// (>= 256 workgroups of 13 blocks): 12 waves x 2 frames (21 / 24 useful) — round 2 ran 16 x 1 there (13 / 16 useful).  Measured and not kept: 4 x 1 at (1, 160000): 10.2 vs 9.1 us;
+// 12 x 1 at two workgroups per CU on the batch: 84 vs 79 us (both still selectable through PAA_SPEC_NW in -DPAA_EXPERIMENTS builds).
+struct SpecGeom { int nw, fpw; };
+static SpecGeom spec_geom(int T, int rows, int op, bool src_spec) {
 #ifdef PAA_EXPERIMENTS
     static const int force = [] { const char* e = getenv("PAA_SPEC_NW"); return e ? atoi(e) : 0; }();
-    if (force == 4 || force == 8 || force == 12 || force == 16) return force;
+    static const int force_fpw = [] { const char* e = getenv("PAA_SPEC_FPW"); return e ? atoi(e) : 1; }();
+    if (force == 4 || force == 8 || force == 12 || force == 16)
+        return SpecGeom{force, (force_fpw == 2 && !src_spec && (force == 12 || force == 16)) ? 2 : 1};
 #endif
-    return rows * cdiv(T - 1, 13) >= 256 ? 16 : 8;
+    if (rows * cdiv(T - 1, 13) < 256) return SpecGeom{8, 1};
+    if (src_spec) return SpecGeom{16, 1};
+    (void)op;
+    return SpecGeom{12, 2};     // 16 x 2 would recompute less halo (3 of 32) but its 128-register budget spills 9..15 registers per lane
 }
 
-template <int OP, bool SRC_SPEC, int NW>
+template <int OP, bool SRC_SPEC, int NW, int FPW>
 paa_status launch_fused_nw(const SpecArgs& a, int rows, hipStream_t st) {
     const int nblk = a.T - 1;                                 // output hop-blocks per row
-    const size_t lds = sizeof(float2) * NW * XB + 256 + ((OP == SOP_FM && NW == 16) ? sizeof(float) * 10 * F : 0);
+    const size_t lds = sizeof(float2) * NW * XB + (FPW == 2 ? sizeof(float) * NW * N : 0) + 256 +
+                       ((OP == SOP_FM && NW * FPW >= 16) ? sizeof(float) * 10 * F : 0);
     if (lds > 64 * 1024) {
         static bool attr = false;
-        if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spec_fused<OP, SRC_SPEC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spec_fused<OP, SRC_SPEC, NW, FPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     }
-    hipLaunchKernelGGL((k_spec_fused<OP, SRC_SPEC, NW>), dim3(cdiv(nblk, NW - 3), rows), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_spec_fused<OP, SRC_SPEC, NW, FPW>), dim3(cdiv(nblk, NW * FPW - 3), rows), dim3(NW * 64), lds, st, a);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }
 
 template <int OP, bool SRC_SPEC>
 paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
-    switch (spec_nw(a.T, rows)) {
-        case 16: return launch_fused_nw<OP, SRC_SPEC, 16>(a, rows, st);
+    const SpecGeom gm = spec_geom(a.T, rows, OP, SRC_SPEC);
+    if (gm.fpw == 2) {
+        if constexpr (!SRC_SPEC) {
 #ifdef PAA_EXPERIMENTS
-        case 12: return launch_fused_nw<OP, SRC_SPEC, 12>(a, rows, st);
-        case 4: return launch_fused_nw<OP, SRC_SPEC, 4>(a, rows, st);
+            if (gm.nw == 16 && OP != SOP_FM) return launch_fused_nw<OP, SRC_SPEC, 16, 2>(a, rows, st);
 #endif
-        default: return launch_fused_nw<OP, SRC_SPEC, 8>(a, rows, st);
+            return launch_fused_nw<OP, SRC_SPEC, 12, 2>(a, rows, st);
+        }
+    }
+    switch (gm.nw) {
+        case 16: return launch_fused_nw<OP, SRC_SPEC, 16, 1>(a, rows, st);
+#ifdef PAA_EXPERIMENTS
+        case 12: return launch_fused_nw<OP, SRC_SPEC, 12, 1>(a, rows, st);
+        case 4: return launch_fused_nw<OP, SRC_SPEC, 4, 1>(a, rows, st);
+#endif
+        default: return launch_fused_nw<OP, SRC_SPEC, 8, 1>(a, rows, st);
     }
 }
 
 }  // namespace
 
-int spec_groups(int T, int rows) { return cdiv(T - 1, spec_nw(T, rows) - 3); }
+int spec_groups(int T, int rows, int op, bool src_spec) {
+    const SpecGeom gm = spec_geom(T, rows, op, src_spec);
+    return cdiv(T - 1, gm.nw * gm.fpw - 3);
+}
 
 paa_status spec_project(const SpecArgs& a, int op, int rows, int* n_part, hipStream_t st) {
     if (a.T < 2) PAA_FAIL(PAA_ERR_SIZE, "spec_project: T=%d", a.T);
-    if (n_part) *n_part = rows * spec_groups(a.T, rows);
+    if (n_part) *n_part = rows * spec_groups(a.T, rows, op, false);
     switch (op) {
         case SOP_MINMAX: return launch_fused<SOP_MINMAX, false>(a, rows, st);
         case SOP_PHON: return launch_fused<SOP_PHON, false>(a, rows, st);
