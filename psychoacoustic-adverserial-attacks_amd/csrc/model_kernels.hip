@@ -1142,6 +1142,100 @@ __global__ __launch_bounds__(128) void k_ctc_rec(const int32_t* __restrict__ lab
     if (wave == 0) recursion(std::true_type{}); else recursion(std::false_type{});
 }
 
+// The same two recursions with ONE WAVE PER STATE SLOT (round 3): 2 NS waves per clip — waves [0, NS) alpha, [NS, 2 NS) beta — wave j
+// of a direction owning state lane * NS + j of every lane.  k_ctc_rec above evaluates its NS states per lane one after the other
+// (six lse3 of ~25 dependent-latency instructions each per time step at S = 150: ~0.5 us per step, 240 us for T = 499, with the rest
+// of the chip idle between the forward and the backward pass); here a step is ONE lse3 per wave plus the exchange of the two
+// neighbour states through a double-buffered LDS array and one workgroup barrier (step t reads buffer t & 1 and writes the other:
+// every wave has finished reading a buffer before any wave passes the next barrier and overwrites it).  Same arithmetic per
+// state, same row layout in the work buffer (k_ctc_grad reads it unchanged): results are bit-identical to k_ctc_rec.
+template <int NS, bool LDS_TAB>
+__global__ __launch_bounds__(128 * NS) void k_ctc_rec_mw(const int32_t* __restrict__ labels, int T, int V, int S_max, int blank,
+                                                          float* __restrict__ nll_out, float* __restrict__ work, int64_t wpc) {
+    static_assert(NS >= 2 && NS <= 8, "one wave per state slot: 4 .. 16 waves");
+    extern __shared__ __attribute__((aligned(16))) double smd[];
+    constexpr int NT = 128 * NS, ROW = 64 * NS;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool fwd = wave < NS;
+    const int j = fwd ? wave : wave - NS;                       // state slot of this wave
+    const int SPmax = 2 * S_max + 1;
+    const CtcWork w = ctc_work(work + (size_t)b * wpc, T, V, ROW);
+    double* xch = smd + (LDS_TAB ? (size_t)T * V : 0);          // [2 directions][2 buffers][NS][64]
+    int* lab = reinterpret_cast<int*>(xch + 4 * ROW);           // [SPmax] extended labels
+    __shared__ int s_len;
+    int* raw = lab + SPmax;                                     // [S_max]
+    for (int s = tid; s < S_max; s += NT) raw[s] = labels[(size_t)b * S_max + s];
+    if (LDS_TAB) {          // lp table -> LDS
+        const int n2 = T * V / 2;
+        const double2* src = reinterpret_cast<const double2*>(w.lp);
+        double2* dst = reinterpret_cast<double2*>(smd);
+        for (int i = tid; i < n2; i += NT) dst[i] = src[i];
+        if (((T * V) & 1) && tid == 0) smd[T * V - 1] = w.lp[T * V - 1];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int k = 0;
+        lab[0] = blank;
+        for (int s = 0; s < S_max; ++s) {
+            const int v = raw[s];
+            if (v >= 0) { lab[2 * k + 1] = v; lab[2 * k + 2] = blank; ++k; }
+        }
+        s_len = k;
+    }
+    const double* tab = LDS_TAB ? smd : w.lp;
+    __syncthreads();
+    const int S = s_len, SP = 2 * S + 1;
+    const int s = lane * NS + j;                                // this lane's state
+    const int l = s < SP ? lab[s] : blank;
+    bool skip;                                                  // the skip transition (s -+ 2) is open
+    if (fwd) skip = s < SP && s >= 2 && l != blank && l != lab[s - 2];
+    else skip = s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l;
+    if (fwd) w.lab[j * 64 + lane] = s < SP ? l : -1;
+    const double skn = skip ? 0.0 : CTC_NEG, dead = s < SP ? 0.0 : CTC_NEG;
+    double* rows = fwd ? w.arow : w.brow;
+    double* xd = xch + (fwd ? 0 : 2 * ROW);                     // this direction's two buffers
+    // neighbours: fwd s - 1, s - 2; bwd s + 1, s + 2 — (slot, lane shift) of each, CTC_NEG past the ends of the wave
+    const int j1 = fwd ? (j >= 1 ? j - 1 : NS - 1) : (j + 1 < NS ? j + 1 : 0);
+    const int j2 = fwd ? (j >= 2 ? j - 2 : NS + j - 2) : (j + 2 < NS ? j + 2 : j + 2 - NS);
+    const int d1 = fwd ? (j >= 1 ? 0 : -1) : (j + 1 < NS ? 0 : 1);
+    const int d2 = fwd ? (j >= 2 ? 0 : -1) : (j + 2 < NS ? 0 : 1);
+    const int l1 = lane + d1, l2 = lane + d2;
+    const bool ok1 = l1 >= 0 && l1 < 64, ok2 = l2 >= 0 && l2 < 64;
+    const int o1 = j1 * 64 + (ok1 ? l1 : 0), o2 = j2 * 64 + (ok2 ? l2 : 0), o0 = j * 64 + lane;
+
+    const int t0 = fwd ? 0 : T - 1;
+    double em = tab[(size_t)t0 * V + l] + dead;
+    const bool on = fwd ? (s == 0 || s == 1) : (s == SP - 1 || s == SP - 2);
+    double a = (on && s < SP) ? em : CTC_NEG;
+    rows[(size_t)t0 * ROW + o0] = a;
+    xd[ROW + o0] = a;                                           // step 1 reads buffer 1
+    if (T > 1) em = tab[(size_t)(fwd ? 1 : T - 2) * V + l] + dead;
+    for (int i = 1; i < T; ++i) {
+        const int t = fwd ? i : T - 1 - i;
+        double emn = 0.0;
+        if (i + 1 < T) emn = tab[(size_t)(fwd ? i + 1 : T - 2 - i) * V + l] + dead;       // next step's emission flies under this step
+        __syncthreads();                                        // every wave's value of the previous step is in buffer i & 1
+        const double* in = xd + (i & 1) * ROW;
+        const double x1 = ok1 ? in[o1] : CTC_NEG;
+        const double x2 = ok2 ? in[o2] : CTC_NEG;
+        a = ctc_lse3(a, x1, x2 + skn) + em;
+        xd[((i + 1) & 1) * ROW + o0] = a;
+        rows[(size_t)t * ROW + o0] = a;
+        em = emn;
+    }
+    __syncthreads();                                            // the last alpha row is in buffer T & 1
+    if (tid == 0) {   // log P = lse(alpha_{T-1}(S'-1), alpha_{T-1}(S'-2))
+        const double* fin = xch + (T & 1) * ROW;
+        const int sa = SP - 1, sb = SP - 2;
+        const double va = fin[(sa % NS) * 64 + sa / NS];
+        const double vb = SP >= 2 ? fin[(sb % NS) * 64 + sb / NS] : CTC_NEG;
+        const double nll = -ctc_lse3(va, vb, CTC_NEG);
+        *w.nll = nll;
+        nll_out[b] = nll < 1e29 ? (float)nll : INFINITY;
+    }
+}
+
 // gradient rows: one wave per frame (grid: frames / 4 x clips)
 template <int NS>
 __global__ __launch_bounds__(256) void k_ctc_grad(int T, int Tpad, int V, float gscale, float* __restrict__ dlogits, Bf dlb,
@@ -1192,6 +1286,24 @@ static paa_status launch_ctc_ws(const float* logits, const int32_t* labels, int 
     PAA_LAUNCH_CHECK();
     const size_t tab = sizeof(double) * (size_t)T * V;
     const size_t small = sizeof(int) * ((size_t)SPmax + S_max) + 64;
+    if constexpr (NS >= 2 && NS <= 8) {       // one wave per state slot (k_ctc_rec_mw)
+        const size_t xch = sizeof(double) * 4 * 64 * NS;
+        const bool ltab = tab + xch + small <= 150 * 1024;
+        const size_t ldsm = xch + small + (ltab ? tab : 0);
+        static bool attr_mw = false;
+        if (!attr_mw) {
+            PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctc_rec_mw<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            attr_mw = true;
+        }
+        if (ltab) hipLaunchKernelGGL((k_ctc_rec_mw<NS, true>), dim3(B), dim3(128 * NS), ldsm, st, labels, T, V, S_max, blank, nll, work, wpc);
+        else hipLaunchKernelGGL((k_ctc_rec_mw<NS, false>), dim3(B), dim3(128 * NS), ldsm, st, labels, T, V, S_max, blank, nll, work, wpc);
+        PAA_LAUNCH_CHECK();
+        if (dlogits) {
+            hipLaunchKernelGGL((k_ctc_grad<NS>), dim3(cdiv(Tpad, 4), B), dim3(256), sizeof(unsigned) * 4 * V, st, T, Tpad, V, gscale, dlogits, dlb, work, wpc);
+            PAA_LAUNCH_CHECK();
+        }
+        return PAA_OK;
+    }
     const bool lds_tab = tab + small <= 150 * 1024;
     const size_t lds = small + (lds_tab ? tab : 0);
     if (lds_tab) {
