@@ -137,11 +137,15 @@ class PgdStepper:
             with torch.cuda.graph(g):
                 r = self.step(p, clean, lab, logits_out=logits_out)
             return g, r
+        # No collective may be in flight while a capture is open (the process group's watchdog thread polls its events), and the
+        # captures only guard THIS thread's launches: the RCCL call between them runs eagerly.
+        torch.cuda.synchronize(self.dev)
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, capture_error_mode="thread_local"):
             r = self._pre(p, clean, lab, True, logits_out)
         torch.distributed.all_reduce(self.packed, op=torch.distributed.ReduceOp.SUM, group=self.group)
-        with torch.cuda.graph(g2):
+        torch.cuda.synchronize(self.dev)
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
             self._post(p, clean)
         r["loss"] = self.stats[ST_LOSS]
         return _SplitGraph(self, g1, g2), r

@@ -111,3 +111,31 @@ def test_load_model_from_local_checkpoint(tmp_path, norm, stable):
     # and the runner end to end on that checkpoint
     rc, rargs = _run(tmp_path / "logs", ["--optimizer_type", "pgd", "--norm_type", "linf", "--model_path", str(ck), "--num_epochs", "1"])
     assert rc == 0 and json.load(open(os.path.join(rargs.save_dir, "results.json")))["finished_training"] == 1.0
+
+
+def test_bench_line_contract():
+    """`python bench.py` (tiny shape so that it takes seconds): ONE JSON line on stdout with the driver's contract — metric / value /
+    ms_per_step / n_gpus / scaling / dtype / data / config.workload — plus the `roofline` object measured live by HIP events around the
+    GEMM launches and the `cpu_baseline` object (the oracle on a bounded sample, labelled as an extrapolated port); the step is replayed
+    from captured hipGraphs except for the sampled step."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--arch", "tiny", "--steps", "4", "--warmup", "1", "--batch", "2", "--seconds", "1",
+                        "--label_tokens", "10", "--cpu_batch", "1", "--cpu_steps", "1", "--no_baseline_faithful", "--no_fft_bench"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                   # stdout carries the one JSON line and nothing else
+    d = json.loads(lines[0])
+    assert d["metric"] == "pgd_steps_per_sec" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3
+    assert "workload" in d["config"] and d["config"]["hip_graph"] is True and d["config"]["hip_graph_replayed_steps"] == 3
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0 and roof["traffic"] is None
+    assert roof["achieved"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["sampled_steps"] == 1
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"].startswith("port") and "extrapolated" in cb["kind"] and cb["sample"]
+    assert "bf16" in d and d["bf16"]["value"] > 0 and "grad_sign_flip_rate" in d["bf16"]["vs_headline_mode"]
