@@ -90,13 +90,6 @@ typedef struct paa_gemm_desc {
     // Cb_il != NULL (precision 1): the bf16 result goes to ONE interleaved array instead of Cb / Cb_lo (which must be NULL):
     // hi of (m, n) at Cb_il[2 (z1 c_s1 + z2 c_s2) + m * 2 ldc + (n / 32) * 64 + n % 32], lo 32 further; ldc, c_s1, c_s2 multiples of 32.
     void* Cb_il;
-    // k_skip > 0 (large operand_bf16 products on the 256 x 256 separate-ring kernels only): columns n >= k_skip_n0 start their K sum at
-    // k = k_skip — their B entries for k < k_skip are zero by construction and are never read.  This is how the two residue-class GEMMs
-    // of a stride-2, 3-tap convolution's input gradient run as ONE product (csrc/model.hip): C (M x 2 Cin) = dy-window (K = 2 Cout:
-    // rows r - 1, r) x [[W_taps 2,0], [0 | W_tap 1]]^T, the second block row needing only row r.  k_skip_n0 must be a multiple of 256,
-    // k_skip a multiple of k_group (whole taps) when k_group > 0, else of 64.  The column tiles of an A panel are dealt to the
-    // persistent workgroups rotated by the panel index, so that long and short tiles alternate on every workgroup.
-    int32_t k_skip_n0, k_skip;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

@@ -701,9 +701,6 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
             PAA_FAIL(PAA_ERR_ARG, "gemm: split precision needs aligned lo planes");
     }
     if (d.a_window && d.a_kseg <= 0) PAA_FAIL(PAA_ERR_ARG, "gemm: a_window needs a_kseg");
-    if (d.k_skip < 0 || (d.k_skip > 0 && (d.k_skip >= d.K || d.k_skip_n0 <= 0 || d.k_skip_n0 >= d.N || (d.k_skip_n0 & 255) ||
-                                          (d.k_skip % (d.k_group > 0 ? d.k_group : 64)) || !d.operand_bf16)))
-        PAA_FAIL(PAA_ERR_ARG, "gemm: k_skip %d / k_skip_n0 %d do not fit K %d, N %d, k_group %d", d.k_skip, d.k_skip_n0, d.K, d.N, d.k_group);
     if (d.act == PAA_ACT_GELU_GRAD && !d.aux) PAA_FAIL(PAA_ERR_ARG, "gemm: GELU_GRAD needs aux");
     GemmArgs g;
     g.d = d;
@@ -796,9 +793,6 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
         if (ring && !ring_cfg_ok(ring, d)) ring = 0;
         if (ring && ring < 20 && d.A_il) ring = 0;               // interleaved A: gemm_ring2.hip and the register-staged kernels
     }
-    if (d.k_skip > 0 && tall) ring = d.precision ? 20 : 21;      // per-tile K ranges: the 256 x 256 separate-ring kernels only, whatever the mode
-    if (d.k_skip > 0 && !((ring == 20 || ring == 21) && ring_cfg_ok(ring, d) && d.N % 256 == 0))
-        PAA_FAIL(PAA_ERR_ARG, "gemm: k_skip needs a product the 256 x 256 ring kernels take (M >= 2048, N %% 256 == 0, K %% 64 == 0; M %d N %d K %d)", d.M, d.N, d.K);
     const int ring_bn = ring == 13 ? 128 : ring ? ring_tile_cols(ring) : 0, ring_bm = ring == 13 ? 192 : ring ? ring_tile_rows(ring) : 0;
     g.tiles_m = cdiv(d.M, ring ? ring_bm : tall ? (bm192 ? 192 : 256) : G_BM);
     g.tiles_n = cdiv(d.N, ring ? ring_bn : bn);
@@ -806,7 +800,7 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     const bool prof = g_prof.on && g_prof.n < g_prof.cap;
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
-        g_prof.flops[g_prof.n] = (2.0 * d.M * d.N * (double)d.K - (d.k_skip > 0 ? 2.0 * d.M * (double)(d.N - d.k_skip_n0) * d.k_skip : 0.0)) * d.batch;
+        g_prof.flops[g_prof.n] = 2.0 * d.M * d.N * (double)d.K * d.batch;
         {   // algorithmic HBM bytes of this product: every operand / result byte once (overlapping conv rows counted once)
             const double es = d.operand_bf16 ? 2.0 * (d.precision ? 2 : 1) : 4.0;
             const double a_el = (d.a_kcontig && d.lda > 0 && d.lda < d.K && !d.a_window && d.a_kseg <= 0) ? ((double)(d.M - 1) * d.lda + d.K) : (double)d.M * d.K;

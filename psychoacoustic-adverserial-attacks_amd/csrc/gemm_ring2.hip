@@ -90,12 +90,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         const int z = t / nwg, orig = t - z * nwg;
         const int q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
         const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-        const int tm = id / g.tiles_n;
-        int tn = id - tm * g.tiles_n;
-        // k_skip: long and short column tiles alternate on every workgroup — the column index is rotated by the ROUND the panel falls
-        // in (a function of the panel alone, so the map stays one-to-one); rotating by tm itself would not do it: a workgroup's panels
-        // are gridDim.x / tiles_n apart
-        if (d.k_skip > 0) { tn += (int)((unsigned)(tm * g.tiles_n) / gridDim.x) % g.tiles_n; if (tn >= g.tiles_n) tn -= g.tiles_n; }
+        const int tm = id / g.tiles_n, tn = id - tm * g.tiles_n;
         c.m0 = tm * BM; c.n0 = tn * BN;
         c.z1 = z / d.batch2; c.z2 = z - c.z1 * d.batch2;
         return c;
@@ -103,38 +98,25 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     // k_group order of the K slabs (gemm.h): kg_spt slabs per tap, kg_taps taps; 0 = plain K order
     const int kg_spt = (d.k_group > 0 && d.k_group % BK == 0 && d.K % d.k_group == 0 && d.K > d.k_group) ? d.k_group / BK : 0;
     const int kg_taps = kg_spt ? d.K / d.k_group : 1;
-    // k_skip (gemm.h): column tiles at n0 >= k_skip_n0 leave out the first k_skip elements of K — whole taps in the k_group order
-    const int skip_n0 = d.k_skip > 0 ? d.k_skip_n0 : 0x7fffffff;
-    const int skip_taps = kg_spt ? d.k_skip / d.k_group : 0, skip_slabs = d.k_skip / BK;
 
     // ---- load cursors: the next (tile, K slab) each operand requests ----------------------------------------------------
-    struct Cursor { int t, k, tap, c, slab, slot, nk_t, tap0, taps_t; };
-    auto enter_tile = [&](Cursor& u) {                 // K range of tile u.t
-        const bool sk = u.t < total && decode(u.t).n0 >= skip_n0;
-        u.k = 0; u.tap = 0; u.c = 0;
-        u.tap0 = sk ? skip_taps : 0;
-        u.taps_t = kg_taps - u.tap0;
-        u.nk_t = kg_spt ? u.taps_t * kg_spt : nk - (sk ? skip_slabs : 0);
-        u.slab = kg_spt ? u.tap0 * kg_spt : (sk ? skip_slabs : 0);
-    };
+    struct Cursor { int t, k, tap, c, slab, slot; };
     auto advance = [&](Cursor& u, int nslots) {        // returns true when the cursor moved on to another tile
         u.slot = u.slot + 1 == nslots ? 0 : u.slot + 1;
         if (kg_spt) {
-            if (++u.tap == u.taps_t) { u.tap = 0; ++u.c; }
-            u.slab = (u.tap0 + u.tap) * kg_spt + u.c;
+            if (++u.tap == kg_taps) { u.tap = 0; ++u.c; }
+            u.slab = u.tap * kg_spt + u.c;
         } else {
             ++u.slab;
         }
-        if (++u.k == u.nk_t) {
+        if (++u.k == nk) {
+            u.k = 0; u.tap = 0; u.c = 0; u.slab = 0;
             u.t += gridDim.x;
-            enter_tile(u);
             return true;
         }
         return false;
     };
-    Cursor ca{(int)blockIdx.x, 0, 0, 0, 0, 0, 0, 0, 0};
-    enter_tile(ca);
-    Cursor cb = ca;
+    Cursor ca{(int)blockIdx.x, 0, 0, 0, 0, 0}, cb = ca;
     const unsigned short* srcA[GA];
     const unsigned short* srcB[GB];
     auto set_srcA = [&](int t) {
@@ -237,8 +219,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        const int nk_cur = cur.n0 >= skip_n0 ? (kg_spt ? (kg_taps - skip_taps) * kg_spt : nk - skip_slabs) : nk;
-        for (int kt = 0; kt < nk_cur; ++kt) {
+        for (int kt = 0; kt < nk; ++kt) {
             // the slots of slab s - 1 are free since the barrier that ended the previous step
             issueB();
             ahead = issueA();
@@ -246,7 +227,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
             const unsigned char* sb = smB + sb_slot * BSZ + brow;
             sa_slot = sa_slot + 1 == NSTA ? 0 : sa_slot + 1;
             sb_slot = sb_slot + 1 == NSTB ? 0 : sb_slot + 1;
-            const bool last = kt + 1 == nk_cur;
+            const bool last = kt + 1 == nk;
             if (!(DEFER && have_first)) {          // first fragments of this slab (else: read under the previous slab's last MFMAs)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {

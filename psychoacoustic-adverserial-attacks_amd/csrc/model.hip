@@ -52,7 +52,6 @@ struct ConvL {
     CBf w;                             // [cout][k*cin]
     std::vector<CBf> wd;               // per residue class of the stride: [cin][(Q+1)*cout]
     std::vector<int> wdQ;
-    CBf wdf;                           // k = 3, s = 2 (optional tensor c{i}.wdf): both residue classes as one [2 cin][2 cout] product (gemm.h, k_skip)
     float *pre = nullptr, *act_f = nullptr, *cv = nullptr, *row_stats = nullptr;
     bool pre16 = false;                // pre holds bf16 (see paa_model::pre16)
     bool gate = false;                 // pre holds gelu'(v) instead of v (both modes; see paa_model::pre16)
@@ -241,11 +240,6 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
                 NEEDB(w, p + ".wd" + std::to_string(rho), (int64_t)c.cin * (Q + 1) * c.cout);
                 c.wd.push_back(w); c.wdQ.push_back(Q);
             }
-            bool fuse = c.k == 3 && c.s == 2 && m->tensors.count(p + ".wdf");
-#ifdef PAA_EXPERIMENTS      // tools/model_ab.py: one product per residue class
-            { const char* e = getenv("PAA_NO_DGFUSE"); if (e && e[0] == '1') fuse = false; }
-#endif
-            if (fuse) NEEDB(c.wdf, p + ".wdf", (int64_t)4 * c.cin * c.cout);
         }
     }
     NEED(m->fp_ln_g, "fp.ln_g", C6); NEED(m->fp_ln_b, "fp.ln_b", C6); NEED(m->fp_b, "fp.b", H);
@@ -612,20 +606,6 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             PAA_TRY(layernorm_bwd(m->gF[ji], c.cv, c.g, c.row_stats, nullptr, nullptr, nullptr, m->gH[ji], B * c.P, c.cout, st));
         const bool out_f32 = a.feat_norm_layer != 0;          // next consumer is an element-wise (LayerNorm backward) kernel
         const Bf& gout = i == 1 ? m->g0H : m->gH[jo];         // conv0's kernels read planar planes; the dgrad GEMMs further up interleaved ones
-        // Both residue classes of a 3-tap, stride-2 layer as ONE product where the 256 x 256 ring kernels take it (gemm.h, k_skip): the
-        // class-1 column tiles walk only the second tap of the window, and dy is read from HBM once instead of once per class — the
-        // class-1 product alone is HBM-bound (3.1 TB/s for 267 algorithmic TFLOP/s at conv1, profiles/r3_step_trace_fp32parity.txt).
-        if (c.wdf.hi && (int64_t)B * c.P >= 2048 && (2 * c.cin) % 256 == 0 && c.cin % 256 == 0 && c.cout % 64 == 0 && c.cout >= 128) {
-            const int64_t ldo = 2 * (int64_t)c.cin;
-            paa_gemm_desc d = gdb(m, ro(m->gH[ji]).off(-(int64_t)c.cout), c.wdf, nullptr, NOBF, B * c.P, 2 * c.cin, 2 * c.cout, c.cout, 2 * c.cout, ldo);
-            d.k_group = kgroup_on() ? c.cout : 0;
-            d.k_skip_n0 = c.cin; d.k_skip = c.cout;
-            if (out_f32) d.C = m->gF[jo]; else set_cb(d, gout);
-            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_gate = pr.gate ? 1 : 0;
-            d.aux = pr.pre;
-            PAA_TRY(gemm(d, st));
-            continue;
-        }
         for (int rho = 0; rho < c.s; ++rho) {
             const int Q = c.wdQ[rho];
             const int64_t ldo = (int64_t)c.s * c.cin;

@@ -28,7 +28,6 @@ def pack_weights(a: Wav2Vec2Arch, sd: dict) -> dict:
       c{i}.w       [O][k*I]           K index j*I + c           (forward, channel-last im2col)
       c{i}.wd{r}   [I][(Q+1)*O]       K index q*O + o  <->  tap j = r + s*(Q - q)
                    (input gradient of the residue class r of the stride, Q = (k-1-r)//s)
-      c{i}.wdf     [2 I][2 O]         k = 3, s = 2 only: [[wd0], [0 | wd1]] — both residue classes as one product (gemm.h, k_skip)
     For the grouped positional conv (weight-norm folded, G groups of Hg channels, K taps):
       pc.w   [G][Hg][K*Hg]   K index j*Hg + c       pc.wd  [G][Hg][K*Hg]  K index j'*Hg + o, tap K-1-j'
     Linear layers keep W ([out][in]) for the forward and W^T for the input gradient.
@@ -49,10 +48,6 @@ def pack_weights(a: Wav2Vec2Arch, sd: dict) -> dict:
                 Q = (k - 1 - r) // s
                 blocks = [W[:, :, r + s * (Q - q)].T for q in range(Q + 1)]     # each [I][O]
                 out[f"c{i}.wd{r}"] = np.concatenate(blocks, axis=1)
-            if k == 3 and s == 2:
-                # both residue classes as ONE product (gemm.h, k_skip): rows [0, I) = class 0 over the window (dy[r - 1], dy[r]);
-                # rows [I, 2 I) = class 1, which only touches dy[r]: zeros in the first half of K, never read by the kernel
-                out[f"c{i}.wdf"] = np.concatenate([out[f"c{i}.wd0"], np.concatenate([np.zeros((I, O), np.float32), out[f"c{i}.wd1"]], axis=1)], axis=0)
         if a.conv_bias:
             out[f"c{i}.b"] = sd[f"{fe}.{i}.conv.bias"]
         if (a.feat_extract_norm == "group" and i == 0) or a.feat_extract_norm == "layer":
@@ -96,7 +91,7 @@ def is_gemm_weight(name: str) -> bool:
     if name == "c0.w":
         return False
     leaf = name.split(".", 1)[1]
-    return leaf in ("w", "wt", "wd", "wqkv", "wqkv_t", "wo", "wo_t", "w1", "w1_t", "w2", "w2_t") or leaf.startswith("wd")      # incl. wdf
+    return leaf in ("w", "wt", "wd", "wqkv", "wqkv_t", "wo", "wo_t", "w1", "w1_t", "w2", "w2_t") or leaf.startswith("wd")
 
 
 def bf16_bits(x: np.ndarray) -> np.ndarray:

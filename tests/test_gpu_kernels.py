@@ -362,64 +362,6 @@ def test_gemm_interleaved_activation_planes(cfg, case):
         assert rel_err(outs[1][0].reshape(M, N), ref) < 1e-4
 
 
-@pytest.mark.parametrize("prec", [1, 0])
-def test_gemm_k_skip_fused_residue_classes(prec):
-    """paa_gemm_desc.k_skip: the two residue-class products of a stride-2, 3-tap convolution's input gradient as ONE product — C (M x 2 Cin)
-    = dy-window (rows r - 1, r: K = 2 Cout) x [[W_taps(2,0)], [0 | W_tap1]]^T with the class-1 column tiles walking only the second tap.
-    Every column tile sums the same products in the same order as the separate product of its class, so the fused result must equal the
-    two separate GEMMs bit for bit (and those are checked against numpy by test_gemm_bf16_operands' dgrad cases)."""
-    from paa_amd.model import bf16_bits, interleave_planes, split_bf16
-    L = _lib.lib()
-    rng = np.random.default_rng(11)
-    Mr, Co, Ci = 4096, 256, 256
-    dy = rng.normal(size=((Mr + 8) * Co)).astype(np.float32)               # 8 guard rows in front: the window reaches one row back
-    wd0 = rng.normal(size=(Ci, 2 * Co)).astype(np.float32) * 0.1          # class 0: taps (2, 0) over rows (r - 1, r)
-    wd1 = rng.normal(size=(Ci, Co)).astype(np.float32) * 0.1              # class 1: tap 1 over row r
-    wdf = np.concatenate([wd0, np.concatenate([np.zeros((Ci, Co), np.float32), wd1], axis=1)], axis=0)
-    gate = rng.uniform(-0.1, 1.1, size=Mr * 2 * Ci).astype(np.float32)
-
-    def planes(x):
-        if prec:
-            hi, lo = split_bf16(x)
-            return torch.from_numpy(hi.view(np.int16)).cuda(), torch.from_numpy(lo.view(np.int16)).cuda()
-        return torch.from_numpy(bf16_bits(x).view(np.int16)).cuda(), None
-    a_hi, a_lo = planes(dy)
-    aux = torch.from_numpy(gate).cuda()
-
-    def run(W, N, K, a_off, c_off, aux_off, out, k_skip=0):
-        w_hi, w_lo = planes(W)
-        d = _lib.PaaGemmDesc()
-        d.A = a_hi.data_ptr() + 2 * a_off
-        d.A_lo = a_lo.data_ptr() + 2 * a_off if prec else None
-        d.B, d.B_lo = w_hi.data_ptr(), (w_lo.data_ptr() if prec else None)
-        d.M, d.N, d.K, d.lda, d.ldb, d.ldc = Mr, N, K, Co, K, 2 * Ci
-        d.a_kcontig = d.b_kcontig = d.batch = d.batch2 = d.operand_bf16 = 1
-        d.precision, d.alpha, d.act, d.aux_gate = prec, 1.0, 2, 1
-        d.aux, d.ld_aux = aux.data_ptr() + 4 * aux_off, 2 * Ci
-        d.k_group = Co
-        d.C = out.data_ptr() + 4 * c_off
-        if k_skip:
-            d.k_skip_n0, d.k_skip = Ci, k_skip
-        _lib.check(L.paa_gemm(C.byref(d), _lib.stream_ptr()))
-        torch.cuda.synchronize()
-        return w_hi, w_lo
-
-    sep = torch.zeros(Mr * 2 * Ci, device="cuda")
-    fused = torch.zeros_like(sep)
-    try:
-        L.paa_gemm_config(20 if prec else 21)              # the separate products on the kernel the fused one runs on (same K-slab width)
-        run(wd0, Ci, 2 * Co, 7 * Co, 0, 0, sep)            # class 0: window starts one row back
-        run(wd1, Ci, Co, 8 * Co, Ci, Ci, sep)              # class 1: row r, columns [Ci, 2 Ci)
-        run(wdf, 2 * Ci, 2 * Co, 7 * Co, 0, 0, fused, k_skip=Co)
-    finally:
-        L.paa_gemm_config(0)
-    assert float(sep.abs().max()) > 0
-    assert torch.equal(sep, fused)
-    ref = (dy.reshape(-1, Co)[7:7 + Mr].astype(np.float64) @ wd0[:, :Co].T.astype(np.float64) +
-           dy.reshape(-1, Co)[8:8 + Mr].astype(np.float64) @ wd0[:, Co:].T.astype(np.float64)) * gate.reshape(Mr, 2 * Ci)[:, :Ci]
-    assert rel_err(fused.cpu().numpy().reshape(Mr, 2 * Ci)[:, :Ci], ref) < (1e-4 if prec else 2e-2)
-
-
 def test_layernorm_fwd_bwd():
     torch.manual_seed(0)
     for rows, cols in ((37, 512), (130, 768), (9, 64), (5, 32)):
