@@ -67,10 +67,6 @@ typedef struct paa_gemm_desc {
     // C_pre[m,n] = gelu'(v), act GELU_GRAD multiplies by aux[m,n] as it stands.  The derivative is evaluated once, next
     // to the GELU that shares its exp, instead of again in every backward epilogue (bf16 mode, together with aux_bf16).
     int32_t aux_gate;
-    // aux_fix16 != 0 (with aux_bf16 and aux_gate; the fp32-parity mode): the 16-bit codes of C_pre / aux are FIXED POINT, not bf16 —
-    // q = rint(gelu'(v) * 43688) + 10922 (paa_common.h, fix16_enc): absolute error 1.1e-5 over the derivative's range [-0.13, 1.13],
-    // the accuracy class of the split-bf16 products themselves, at half the bytes of the f32 array this mode kept through round 2.
-    int32_t aux_fix16;
     // k_group > 0 (operand_bf16 products whose A rows are OVERLAPPING windows: strided convolutions, K = taps * k_group,
     // lda < K): the K slabs are walked channel-slab-major, tap-minor — slab (c, tap) = elements tap * k_group + c * BK ..
     // — instead of 0 .. K in order.  Consecutive output rows share input frames between taps (row r's tap 2 is row

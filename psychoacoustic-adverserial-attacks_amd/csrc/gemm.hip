@@ -702,7 +702,6 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     }
     if (d.a_window && d.a_kseg <= 0) PAA_FAIL(PAA_ERR_ARG, "gemm: a_window needs a_kseg");
     if (d.act == PAA_ACT_GELU_GRAD && !d.aux) PAA_FAIL(PAA_ERR_ARG, "gemm: GELU_GRAD needs aux");
-    if (d.aux_fix16 && !(d.aux_bf16 && d.aux_gate)) PAA_FAIL(PAA_ERR_ARG, "gemm: aux_fix16 codes a kept gelu'(v): it needs aux_bf16 (16-bit storage) and aux_gate");
     GemmArgs g;
     g.d = d;
     const bool narrow = d.N <= 64;

@@ -48,8 +48,7 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
     // mw / nw: first row / column this lane owns
     const int64_t coff = z1 * d.c_s1 + z2 * d.c_s2 + (int64_t)mw * d.ldc + nw;
     float* __restrict__ C = d.C ? d.C + coff : nullptr;
-    const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored in 16 bits: bf16, or fixed-point codes (aux_fix16)
-    const bool fix = d.aux_fix16 != 0;
+    const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored as bf16
     float* __restrict__ Cp = (d.C_pre && !x16) ? d.C_pre + coff : nullptr;
     unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + coff : nullptr;
     unsigned short* __restrict__ Cb = d.Cb ? reinterpret_cast<unsigned short*>(d.Cb) + coff : nullptr;
@@ -88,7 +87,7 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int dm = (e & 3) + 8 * (e >> 2);
-                    ax[e] = (mw + i * 32 + dm < d.M) ? (auxi16 ? (fix ? fix16_dec(auxi16[dm * ld_aux + dn]) : bf16_to_f32(auxi16[dm * ld_aux + dn])) : auxi[dm * ld_aux + dn]) : 0.f;
+                    ax[e] = (mw + i * 32 + dm < d.M) ? (auxi16 ? bf16_to_f32(auxi16[dm * ld_aux + dn]) : auxi[dm * ld_aux + dn]) : 0.f;
                 }
             }
 #pragma unroll
@@ -106,7 +105,7 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
                 if (act == PAA_ACT_GELU) {
                     const float keep = d.aux_gate ? gelu_grad_f(v) : v;
                     if (Cpi) Cpi[ci] = dead ? 0.f : keep;
-                    if (Cpi16) Cpi16[ci] = fix ? (unsigned short)(dead ? FIX16_ZERO : fix16_enc(keep)) : (dead ? (unsigned short)0 : bf16_bits(keep));
+                    if (Cpi16) Cpi16[ci] = dead ? (unsigned short)0 : bf16_bits(keep);
                     v = gelu_f(v);
                 } else if (act == PAA_ACT_GELU_GRAD) {
                     v *= d.aux_gate ? ax[e] : gelu_grad_f(ax[e]);
@@ -174,8 +173,7 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
     const bool gg = act == PAA_ACT_GELU_GRAD;
     const int64_t cbase = z1 * d.c_s1 + z2 * d.c_s2;
     float* __restrict__ C = d.C ? d.C + cbase : nullptr;
-    const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored in 16 bits: bf16, or fixed-point codes (aux_fix16)
-    const bool fix = d.aux_fix16 != 0;
+    const bool x16 = d.aux_bf16 != 0;                   // C_pre / aux stored as bf16
     const bool gate = d.aux_gate != 0;                  // C_pre / aux hold gelu'(v)
     float* __restrict__ Cp = (d.C_pre && !x16) ? d.C_pre + cbase : nullptr;
     unsigned short* __restrict__ Cp16 = (d.C_pre && x16) ? reinterpret_cast<unsigned short*>(d.C_pre) + cbase : nullptr;
@@ -247,13 +245,8 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
             float e4[4];
             if (ex16) {
                 const unsigned w0 = j ? xv[u][0].z : xv[u][0].x, w1 = j ? xv[u][0].w : xv[u][0].y;
-                if (fix) {
-                    e4[0] = fix16_dec(w0 & 0xFFFFu); e4[1] = fix16_dec(w0 >> 16);
-                    e4[2] = fix16_dec(w1 & 0xFFFFu); e4[3] = fix16_dec(w1 >> 16);
-                } else {
-                    e4[0] = __uint_as_float(w0 << 16); e4[1] = __uint_as_float(w0 & 0xFFFF0000u);
-                    e4[2] = __uint_as_float(w1 << 16); e4[3] = __uint_as_float(w1 & 0xFFFF0000u);
-                }
+                e4[0] = __uint_as_float(w0 << 16); e4[1] = __uint_as_float(w0 & 0xFFFF0000u);
+                e4[2] = __uint_as_float(w1 << 16); e4[3] = __uint_as_float(w1 & 0xFFFF0000u);
             } else {
                 e4[0] = __uint_as_float(xv[u][j].x); e4[1] = __uint_as_float(xv[u][j].y);
                 e4[2] = __uint_as_float(xv[u][j].z); e4[3] = __uint_as_float(xv[u][j].w);
@@ -279,13 +272,8 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
                 }
                 if (Cp && live) *reinterpret_cast<float4*>(Cp + ci + 4u * j) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kp[0], kp[1], kp[2], kp[3]);
                 if (Cp16) {
-                    if (fix) {
-                        pp[2 * j] = dead ? (FIX16_ZERO | (FIX16_ZERO << 16)) : (fix16_enc(kp[0]) | (fix16_enc(kp[1]) << 16));
-                        pp[2 * j + 1] = dead ? (FIX16_ZERO | (FIX16_ZERO << 16)) : (fix16_enc(kp[2]) | (fix16_enc(kp[3]) << 16));
-                    } else {
-                        pp[2 * j] = dead ? 0u : bf16_pack2(kp[0], kp[1]);
-                        pp[2 * j + 1] = dead ? 0u : bf16_pack2(kp[2], kp[3]);
-                    }
+                    pp[2 * j] = dead ? 0u : bf16_pack2(kp[0], kp[1]);
+                    pp[2 * j + 1] = dead ? 0u : bf16_pack2(kp[2], kp[3]);
                 }
                 if (ex) {
 #pragma unroll

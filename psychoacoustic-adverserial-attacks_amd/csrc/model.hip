@@ -114,7 +114,6 @@ struct paa_model {
                                      // interleaved per 32-element group (paa_common.h Bf::il; gemm.h A_il / Cb_il)
     bool fused;                      // flash-style attention kernels (head_dim 64); else materialised scores
     bool gate;                       // see pre16; false only in -DPAA_EXPERIMENTS builds under PAA_NO_GATE32=1 (fp32-parity A/B)
-    bool prefix;                     // pre16 arrays hold fixed-point codes (fp32-parity mode) instead of bf16
     bool pre16;                      // What a GELU keeps for its backward pass (L{l}.fpre, and conv{i}.pre, i < last, of the
                                      // group-norm extractor) is the derivative gelu'(v) itself in BOTH modes (paa_gemm_desc.aux_gate;
                                      // ConvL::gate): it only ever multiplies a gradient, and evaluating it next to the GELU that
@@ -184,14 +183,10 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     paa_model* m = new paa_model();
     m->a = a; m->Bmax = max_batch; m->L = length; m->prec = precision ? 1 : 0;
     m->fused = a.hidden / a.heads == 64;      // flash-style kernels; split-bf16 (hi + lo planes) in fp32-parity mode
+    m->pre16 = m->prec == 0;
     m->gate = true;
 #ifdef PAA_EXPERIMENTS      // tools/gate_ab.py: raw pre-activations in fp32-parity mode
-    { const char* e = getenv("PAA_NO_GATE32"); m->gate = m->prec == 0 || !(e && e[0] == '1'); }
-#endif
-    m->pre16 = m->gate;                  // a kept derivative is stored in 16 bits in BOTH modes ...
-    m->prefix = m->gate && m->prec == 1; // ... as bf16 in bf16 mode, as fixed-point codes in fp32-parity mode (gemm.h, aux_fix16)
-#ifdef PAA_EXPERIMENTS      // tools/model_ab.py: the f32 array of rounds 1-2
-    { const char* e = getenv("PAA_NO_FIX16"); if (e && e[0] == '1' && m->prec == 1) { m->pre16 = false; m->prefix = false; } }
+    { const char* e = getenv("PAA_NO_GATE32"); m->gate = m->pre16 || !(e && e[0] == '1'); }
 #endif
     m->ail = m->prec == 1 && a.hidden % 32 == 0 && a.ffn % 32 == 0;
     for (int i = 0; i < a.n_conv; ++i) m->ail = m->ail && a.conv_dim[i] % 32 == 0;
@@ -384,7 +379,6 @@ static paa_status linear(const paa_model* m, CBf x, CBf w, const float* bias, fl
     paa_gemm_desc d = gdb(m, x, w, y, yb, M, N, K, K, K, N);
     d.bias = bias; d.residual = residual; d.ld_res = N; d.act = act; d.C_pre = pre; d.aux = aux; d.ld_aux = N;
     d.aux_bf16 = x16 ? 1 : 0;
-    d.aux_fix16 = (x16 && m->prefix) ? 1 : 0;
     d.aux_gate = (m->gate && (act == PAA_ACT_GELU || act == PAA_ACT_GELU_GRAD)) ? 1 : 0;     // kept pre-activations hold gelu'(v) (paa_model::pre16)
     return gemm(d, st);
 }
@@ -399,7 +393,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         Conv0Args ca{};
         ca.clean = clean; ca.p = p; ca.clamp = clamp; ca.B = B; ca.L = m->L; ca.T = c.T; ca.P = c.P; ca.C = c.cout;
         ca.k = c.k; ca.stride = c.s; ca.w = c.w0; ca.bias = c.b; ca.gamma = c.g; ca.beta = c.beta; ca.eps = 1e-5f;
-        ca.pre = c.pre; ca.pre16 = c.pre16; ca.prefix = c.pre16 && m->prefix; ca.gate = c.gate; ca.actb = c.actb; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
+        ca.pre = c.pre; ca.pre16 = c.pre16; ca.gate = c.gate; ca.actb = c.actb; ca.gn_stats = m->gn_stats; ca.row_stats = c.row_stats;
         if (a.feat_norm_layer) PAA_TRY(conv0_ln_forward(ca, st)); else PAA_TRY(conv0_gn_forward(ca, m->c0_part, st));
     }
     for (int i = 1; i < nc; ++i) {
@@ -416,7 +410,7 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
             PAA_TRY(layernorm_fwd(c.cv, c.g, c.beta, c.pre, c.row_stats, B * c.P, c.cout, 1e-5f, NOBF, last ? NOBF : c.actb,
                                   last ? c.act_f : nullptr, st));
         } else {
-            d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.aux_fix16 = (c.pre16 && m->prefix) ? 1 : 0; d.aux_gate = c.gate ? 1 : 0; d.act = PAA_ACT_GELU;
+            d.C_pre = c.pre; d.aux_bf16 = c.pre16 ? 1 : 0; d.aux_gate = c.gate ? 1 : 0; d.act = PAA_ACT_GELU;
             if (last) d.C = c.act_f; else set_cb(d, c.actb);
             PAA_TRY(gemm(d, st));
         }
@@ -629,7 +623,7 @@ static paa_status backward(paa_model* m, const float* clean, const float* p, int
             d.k_group = kgroup_on() ? c.cout : 0;
             if (out_f32) d.C = m->gF[jo] + (int64_t)rho * c.cin;
             else set_cb(d, boff(gout, (int64_t)rho * c.cin));
-            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_fix16 = (pr.pre16 && m->prefix) ? 1 : 0; d.aux_gate = pr.gate ? 1 : 0;
+            d.act = PAA_ACT_GELU_GRAD; d.ld_aux = ldo; d.aux_bf16 = pr.pre16 ? 1 : 0; d.aux_gate = pr.gate ? 1 : 0;
             d.aux = pr.pre16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(pr.pre) + (int64_t)rho * c.cin)
                              : pr.pre + (int64_t)rho * c.cin;
             PAA_TRY(gemm(d, st));
@@ -723,13 +717,12 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
     const int64_t M = (int64_t)B * m->P;
     const float* p = nullptr;
     Bf pb = NOBF;
-    bool fixcodes = false;           // pb.hi holds fixed-point codes of a kept gelu' (fp32-parity mode)
     int64_t cnt = 0;
     for (int i = 0; i < nc && !p && !pb.hi; ++i) {
         const ConvL& c = m->conv[i];
         const std::string b = "conv" + std::to_string(i);
         const int64_t sz = (int64_t)B * c.P * c.cout;
-        if (n == b + ".pre") { if (c.pre16) { pb = Bf{reinterpret_cast<unsigned short*>(c.pre), nullptr}; fixcodes = m->prefix; } else p = c.pre; cnt = sz; }
+        if (n == b + ".pre") { if (c.pre16) pb = Bf{reinterpret_cast<unsigned short*>(c.pre), nullptr}; else p = c.pre; cnt = sz; }
         else if (n == b + ".act") { if (c.act_f) p = c.act_f; else pb = c.actb; cnt = sz; }
         else if (n == b + ".cv" && c.cv) { p = c.cv; cnt = sz; }
     }
@@ -739,7 +732,7 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
         if (n == b + ".qkv") { if (e.qkv) p = e.qkv; else pb = e.qkvH; cnt = M * 3 * H; }
         else if (n == b + ".P" && e.P) { p = e.P; cnt = (int64_t)B * a.heads * m->Tp * m->Tp; }
         else if (n == b + ".ln1_in") { p = e.ln1_in; cnt = M * H; }
-        else if (n == b + ".fpre") { if (m->pre16) { pb = Bf{reinterpret_cast<unsigned short*>(e.fpre), nullptr}; fixcodes = m->prefix; } else p = e.fpre; cnt = M * F; }
+        else if (n == b + ".fpre") { if (m->pre16) pb = Bf{reinterpret_cast<unsigned short*>(e.fpre), nullptr}; else p = e.fpre; cnt = M * F; }
         else if (n == b + ".ln2_in") { p = e.ln2_in; cnt = M * H; }
     }
     if (!p && !pb.hi) {
@@ -781,10 +774,6 @@ extern "C" int64_t paa_model_debug_read(paa_model* m, const char* name, float* h
             }
             std::vector<unsigned short> hi(nn), lo(pb.lo ? nn : 0);
             if (hipMemcpy(hi.data(), pb.hi, 2 * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-            if (fixcodes) {           // paa_common.h fix16_dec
-                for (int64_t i = 0; i < nn; ++i) host[i] = ((float)hi[i] - 10922.f) * (1.f / 43688.f);
-                return cnt;
-            }
             if (pb.lo && hipMemcpy(lo.data(), pb.lo, 2 * nn, hipMemcpyDeviceToHost) != hipSuccess) return -1;
             for (int64_t i = 0; i < nn; ++i) {
                 uint32_t u = (uint32_t)hi[i] << 16;

@@ -34,7 +34,6 @@ struct Conv0Args {
     float eps;
     float* pre;              // (B, P, C) norm output (pre-GELU); when pre16 (group-norm forward only): bf16 storage of gelu'(.)
     int pre16;
-    int prefix;              // with pre16: the 16-bit codes are fixed point (paa_common.h fix16_enc; fp32-parity mode), not bf16
     int gate;                // group-norm forward: pre keeps gelu'(.) (f32 unless pre16)
     Bf actb;                 // (B, P, C) GELU(pre) as bf16 planes (the next conv's GEMM operand)
     float* gn_stats;         // group: (B, C, 2) mean, rstd over time

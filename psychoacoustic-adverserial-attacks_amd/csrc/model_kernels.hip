@@ -269,8 +269,7 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                         if (a.pre16) {                       // bf16 mode: keep gelu'(y) as bf16
                             f32x2 dg;
                             g = gelu_both_fast2(y, dg);
-                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(a.pre) + o) =
-                                a.prefix ? (fix16_enc(dg.x) | (fix16_enc(dg.y) << 16)) : (bf16_bits(dg.x) | ((unsigned)bf16_bits(dg.y) << 16));
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(a.pre) + o) = bf16_bits(dg.x) | ((unsigned)bf16_bits(dg.y) << 16);
                         } else if (a.gate) {                 // fp32-parity mode: keep gelu'(y) as f32; the branch-free erf (|error| <= 1.5e-7)
                             f32x2 dg;                        // of every other GELU of this mode (gemm_dev.h, epilogue_vec): with libm's erff for
                             g = gelu_both_fast2(y, dg);      // both the GELU and its derivative this HBM-sized kernel turns VALU-bound (+1 % of the step)
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                     if (a.pre16) {
                         float dg;
                         const float gy = gelu_both_fast(y, dg);
-                        reinterpret_cast<unsigned short*>(a.pre)[o] = a.prefix ? (unsigned short)fix16_enc(dg) : bf16_bits(dg);
+                        reinterpret_cast<unsigned short*>(a.pre)[o] = bf16_bits(dg);
                         store_bf16(a.actb, o, gy);
                     } else if (a.gate) {
                         float dg;
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
         for (int t = a.T; t < a.P; ++t)
             for (int c = threadIdx.x; c < a.C; c += 256) {
                 const size_t o = ((size_t)b * a.P + t) * a.C + c;
-                if (a.pre16) reinterpret_cast<unsigned short*>(a.pre)[o] = a.prefix ? (unsigned short)FIX16_ZERO : (unsigned short)0; else a.pre[o] = 0.f;
+                if (a.pre16) reinterpret_cast<unsigned short*>(a.pre)[o] = 0; else a.pre[o] = 0.f;
                 store_bf16(a.actb, o, 0.f);
             }
 }

@@ -117,14 +117,6 @@ __device__ __forceinline__ void store_bf16x4(const Bf& o, size_t i, const float 
     }
 }
 
-// 16-bit fixed-point code of a kept GELU derivative (gemm.h, aux_fix16; fp32-parity mode): gelu'(v) lies in [-0.129, 1.129], so
-// q = rint(g * 43688) + 10922 fits 16 bits with an ABSOLUTE error of 1.1e-5 — below the 1.5e-5 relative error the split-bf16 products
-// it multiplies carry themselves — where bf16 would give 2e-3 and f32 costs twice the bytes.  0 and 1 are exact codes.
-constexpr float FIX16_S = 43688.f, FIX16_O = 10922.f;
-constexpr unsigned FIX16_ZERO = 10922u;
-__device__ __forceinline__ unsigned fix16_enc(float g) { return (unsigned)__builtin_rintf(fmaf(g, FIX16_S, FIX16_O)) & 0xFFFFu; }
-__device__ __forceinline__ float fix16_dec(unsigned q) { return ((float)q - FIX16_O) * (1.f / FIX16_S); }
-
 // exact (erf) GELU and its derivative, as torch.nn.functional.gelu(approximate='none')
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

@@ -5,8 +5,7 @@ device: one model per variant at the headline shape, timed in alternating rounds
     gpurun -- 'PAA_EXTRA_HIPCC_FLAGS=-DPAA_EXPERIMENTS python tools/model_ab.py default no_ail no_c0dma'
 
 Variants: default = the shipped behaviour; no_ail = planar activation planes instead of the interleaved ones (gemm.h A_il / Cb_il;
-read at model creation); no_c0dma = the register-staged conv0 GroupNorm backward instead of the LDS-DMA one (read per launch);
-no_fix16 = the kept GELU derivatives as f32 arrays (rounds 1-2) instead of 16-bit fixed-point codes (gemm.h aux_fix16; model creation).
+read at model creation); no_c0dma = the register-staged conv0 GroupNorm backward instead of the LDS-DMA one (read per launch).
 """
 import json
 import os
@@ -24,8 +23,8 @@ from paa_amd.training_utils import parser
 from paa_amd.training_utils.pgd import PgdStepper
 
 
-VARIANTS = {"default": {}, "no_ail": {"PAA_NO_AIL": "1"}, "no_c0dma": {"PAA_NO_C0DMA": "1"}, "no_fix16": {"PAA_NO_FIX16": "1"}}
-SWITCHES = ("PAA_NO_AIL", "PAA_NO_C0DMA", "PAA_NO_FIX16")
+VARIANTS = {"default": {}, "no_ail": {"PAA_NO_AIL": "1"}, "no_c0dma": {"PAA_NO_C0DMA": "1"}}
+SWITCHES = ("PAA_NO_AIL", "PAA_NO_C0DMA")
 
 
 def set_env(name):
