@@ -1,4 +1,4 @@
-"""In-kernel clock held under the ring GEMM kernels (diagnostic build: PAA_EXTRA_HIPCC_FLAGS=-DPAA_CLOCK_STAMP):
+"""In-kernel clock held under the ring GEMM kernels (diagnostic build: PAA_EXTRA_HIPCC_FLAGS="-DPAA_EXPERIMENTS -DPAA_CLOCK_STAMP"):
 shader ticks / 100 MHz real-time ticks around each workgroup's tile loop, after >= 2 s of back-to-back launches on random
 data.  Prints GHz per (precision, shape).  The shipped library carries no stamps."""
 import ctypes as C

@@ -1,5 +1,5 @@
 """In-process A/B of the fp32-parity PGD step with the one-pass conv0 GroupNorm backward (default) against the two-pass
-path (PAA_CONV0_TWO_PASS=1, read per call) — run on the GPU box."""
+path (the ABI's test hook paa_test_option(0, 1), read per call) — run on the GPU box."""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from paa_amd import arch as A, synth
+from paa_amd import _lib, arch as A, synth
 from paa_amd.core import loss_helpers
 from paa_amd.model import PaaModel
 from paa_amd.training_utils import parser
@@ -28,7 +28,7 @@ def main(steps=15, rounds=3, dtype="fp32"):
     best = {}
     for rnd in range(rounds + 1):
         for two in ("0", "1"):
-            os.environ["PAA_CONV0_TWO_PASS"] = two
+            _lib.check(_lib.lib().paa_test_option(0, int(two)))
             for _ in range(2):
                 st.step(p, clean, labels, want_logits=False)
             torch.cuda.synchronize()
@@ -40,6 +40,7 @@ def main(steps=15, rounds=3, dtype="fp32"):
             if rnd:
                 best[two] = min(best.get(two, 1e9), ms)
             print(f"round {rnd} two_pass={two}: {ms:.3f} ms", flush=True)
+    _lib.lib().paa_test_option(0, 0)
     print({("two_pass" if k == "1" else "one_pass"): round(v, 3) for k, v in best.items()})
 
 

@@ -1,5 +1,6 @@
 """In-process A/B of the fp32-parity PGD step with gelu'(v) kept by the forward pass (default) against the raw pre-activation
-(PAA_NO_GATE32=1 at model creation: the backward epilogues evaluate gelu' themselves) — run on the GPU box."""
+(PAA_NO_GATE32=1 at model creation: the backward epilogues evaluate gelu' themselves) — run on the GPU box with the diagnostic
+library, the only one that reads the switch:  PAA_EXTRA_HIPCC_FLAGS=-DPAA_EXPERIMENTS python tools/gate_ab.py"""
 import os
 import sys
 import time

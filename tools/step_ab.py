@@ -1,6 +1,10 @@
 """In-process A/B of the whole PGD step under two paa_gemm kernel selections (run on the GPU box): ring kernels in their
 automatic selection (config 0) against the register-staged kernels only (config 1), interleaved rounds on one device —
-the only comparison that survives the +-4 % spread between gpurun boxes."""
+the only comparison that survives the +-4 % spread between gpurun boxes.  The switches exist only in the diagnostic library:
+
+    PAA_EXTRA_HIPCC_FLAGS=-DPAA_EXPERIMENTS python psychoacoustic-adverserial-attacks_amd/build_ext.py      # here
+    gpurun -- 'PAA_EXTRA_HIPCC_FLAGS=-DPAA_EXPERIMENTS python tools/step_ab.py'
+"""
 import os
 import sys
 import time
