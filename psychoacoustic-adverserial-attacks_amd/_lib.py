@@ -51,7 +51,8 @@ class PaaGemmDesc(C.Structure):
                 ("accumulate", C.c_int32), ("precision", C.c_int32),
                 ("operand_bf16", C.c_int32), ("A_lo", C.c_void_p), ("B_lo", C.c_void_p), ("Cb", C.c_void_p),
                 ("Cb_lo", C.c_void_p), ("aux_bf16", C.c_int32), ("aux_gate", C.c_int32), ("k_group", C.c_int32), ("B_il", C.c_void_p),
-                ("A_il", C.c_void_p), ("Cb_il", C.c_void_p)]
+                ("A_il", C.c_void_p), ("Cb_il", C.c_void_p),
+                ("res_ln_stats", C.c_void_p), ("res_ln_g", C.c_void_p), ("res_ln_b", C.c_void_p)]
 
 
 _SIGS = {

@@ -90,6 +90,14 @@ typedef struct paa_gemm_desc {
     // Cb_il != NULL (precision 1): the bf16 result goes to ONE interleaved array instead of Cb / Cb_lo (which must be NULL):
     // hi of (m, n) at Cb_il[2 (z1 c_s1 + z2 c_s2) + m * 2 ldc + (n / 32) * 64 + n % 32], lo 32 further; ldc, c_s1, c_s2 multiples of 32.
     void* Cb_il;
+    // res_ln_stats != NULL (batch = 1 products with a residual): the residual is the LayerNorm of the array `residual` points at,
+    // evaluated on the fly — r[m, n] = (residual[m, n] - mean_m) * rstd_m * res_ln_g[n] + res_ln_b[n] with (mean_m, rstd_m) =
+    // res_ln_stats[2 m], [2 m + 1] as k_ln_fwd left them.  The post-LN encoder adds LN(x) to its attention / FFN outputs; with
+    // this mode the LayerNorm kernel writes only the bf16 planes the next GEMM reads, not an f32 copy for the residual (-4 of the 12
+    // bytes per element it moves).  Same arithmetic as the LayerNorm kernel.
+    const float* res_ln_stats;
+    const float* res_ln_g;
+    const float* res_ln_b;
 } paa_gemm_desc;
 
 #ifdef __cplusplus

@@ -702,6 +702,9 @@ paa_status gemm(const paa_gemm_desc& d, hipStream_t st) {
     }
     if (d.a_window && d.a_kseg <= 0) PAA_FAIL(PAA_ERR_ARG, "gemm: a_window needs a_kseg");
     if (d.act == PAA_ACT_GELU_GRAD && !d.aux) PAA_FAIL(PAA_ERR_ARG, "gemm: GELU_GRAD needs aux");
+    if (d.res_ln_stats && (!d.residual || !d.res_ln_g || !d.res_ln_b || d.batch != 1 || d.act == PAA_ACT_GELU_GRAD ||
+                           ((uintptr_t)d.res_ln_stats & 7) || ((uintptr_t)d.res_ln_g & 15) || ((uintptr_t)d.res_ln_b & 15)))
+        PAA_FAIL(PAA_ERR_ARG, "gemm: res_ln_stats needs a residual, gain and bias (16-byte aligned), batch 1 and no GELU_GRAD");
     GemmArgs g;
     g.d = d;
     const bool narrow = d.N <= 64;

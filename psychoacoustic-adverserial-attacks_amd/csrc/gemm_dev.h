@@ -110,7 +110,14 @@ __device__ __forceinline__ void epilogue(const paa_gemm_desc& d, f32x16 (&acc)[M
                 } else if (act == PAA_ACT_GELU_GRAD) {
                     v *= d.aux_gate ? ax[e] : gelu_grad_f(ax[e]);
                 }
-                if (resi) v += resi[dm * ld_res + dn];
+                if (resi) {
+                    float rv = resi[dm * ld_res + dn];
+                    if (d.res_ln_stats) {          // residual = LayerNorm(stored input), gemm.h
+                        const int gm = mw + i * 32 + dm, gn = nw + dn;
+                        rv = (rv - d.res_ln_stats[2 * (size_t)gm]) * d.res_ln_stats[2 * (size_t)gm + 1] * d.res_ln_g[gn] + d.res_ln_b[gn];
+                    }
+                    v += rv;
+                }
                 if (dead) v = 0.f;
                 if (Ci) {
                     if (d.accumulate) v += Ci[ci];
@@ -201,6 +208,17 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
         const float4 b1 = *reinterpret_cast<const float4*>(bp + (unsigned)col + 4u);
         bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
     }
+    // residual = LayerNorm(stored input) (gemm.h, res_ln_stats): gain / bias of this lane's 8 columns
+    const bool rln = d.res_ln_stats != nullptr && !gg && ex != nullptr;
+    float lg[8], lb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { lg[k] = 1.f; lb[k] = 0.f; }
+    if (rln && col_ok) {
+        const float4 g0 = *reinterpret_cast<const float4*>(d.res_ln_g + (unsigned)col), g1 = *reinterpret_cast<const float4*>(d.res_ln_g + (unsigned)col + 4u);
+        const float4 b0 = *reinterpret_cast<const float4*>(d.res_ln_b + (unsigned)col), b1 = *reinterpret_cast<const float4*>(d.res_ln_b + (unsigned)col + 4u);
+        lg[0] = g0.x; lg[1] = g0.y; lg[2] = g0.z; lg[3] = g0.w; lg[4] = g1.x; lg[5] = g1.y; lg[6] = g1.z; lg[7] = g1.w;
+        lb[0] = b0.x; lb[1] = b0.y; lb[2] = b0.z; lb[3] = b0.w; lb[4] = b1.x; lb[5] = b1.y; lb[6] = b1.z; lb[7] = b1.w;
+    }
     const int period = d.row_period;
     const int mrem0 = period > 0 ? row0 % period : 0;
     const float alpha = d.alpha;
@@ -235,6 +253,8 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
             dead = rem >= d.row_valid;
         }
         const unsigned ci = co + (unsigned)dm * ldc;
+        float2 rst = make_float2(0.f, 1.f);                  // (mean, rstd) of this lane's row of the group (res_ln_stats)
+        if (rln && live) rst = *reinterpret_cast<const float2*>(d.res_ln_stats + 2 * (size_t)(row0 + dm));
         unsigned hp[4], lp[4], pp[4];                        // packed bf16 pairs of the 8 columns (result hi / lo, C_pre)
         // the two 4-column halves go through the math one after the other: with the tile's 64 accumulator registers
         // still live there is no room for eight interleaved GELU chains
@@ -250,6 +270,10 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
             } else {
                 e4[0] = __uint_as_float(xv[u][j].x); e4[1] = __uint_as_float(xv[u][j].y);
                 e4[2] = __uint_as_float(xv[u][j].z); e4[3] = __uint_as_float(xv[u][j].w);
+            }
+            if (rln) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e4[k] = (e4[k] - rst.x) * rst.y * lg[4 * j + k] + lb[4 * j + k];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = x[k] * alpha + bv[4 * j + k];

@@ -109,6 +109,9 @@ struct paa_model {
     paa_arch a;
     int Bmax, L, prec;
     int T, P, Tp, M;                 // encoder frames, padded frames per clip, score-matrix ld, Bmax * P
+    bool rln;                        // post-LN encoder: the residual LN(x) of the attention / FFN output products is evaluated in their
+                                     // epilogues from x and the LayerNorm statistics (gemm.h, res_ln_stats); the LayerNorm kernels then
+                                     // write bf16 planes only.  false only in -DPAA_EXPERIMENTS builds under PAA_NO_RLN=1
     bool ail;                        // fp32-parity mode: the activation planes that only GEMMs read (conv stack outputs and gradients, the
                                      // LayerNorm outputs that feed QKV / FFN products, the FFN hidden activation and its gradient) are kept
                                      // interleaved per 32-element group (paa_common.h Bf::il; gemm.h A_il / Cb_il)
@@ -187,6 +190,10 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
     m->gate = true;
 #ifdef PAA_EXPERIMENTS      // tools/gate_ab.py: raw pre-activations in fp32-parity mode
     { const char* e = getenv("PAA_NO_GATE32"); m->gate = m->pre16 || !(e && e[0] == '1'); }
+#endif
+    m->rln = true;
+#ifdef PAA_EXPERIMENTS      // tools/model_ab.py: f32 LayerNorm outputs read back as residuals
+    { const char* e = getenv("PAA_NO_RLN"); if (e && e[0] == '1') m->rln = false; }
 #endif
     m->ail = m->prec == 1 && a.hidden % 32 == 0 && a.ffn % 32 == 0;
     for (int i = 0; i < a.n_conv; ++i) m->ail = m->ail && a.conv_dim[i] % 32 == 0;
@@ -311,7 +318,8 @@ extern "C" paa_status paa_model_create(paa_model** out, const paa_arch* arch, co
         m->gz = take(MC);
         m->fnH = take_bf(MC); m->fp_stats = take((int64_t)m->M * 2);
         m->h0 = take(MH); m->h0H = take_bf(MH); m->pos_pre = take(MH); m->hsum = take(MH); m->enc_stats = take((int64_t)m->M * 2);
-        m->xa = take(MH); m->xaH = take_bf(MH, m->ail); m->xb = take(MH); m->xbH = take_bf(MH, m->ail);
+        m->xaH = take_bf(MH, m->ail); m->xbH = take_bf(MH, m->ail);
+        m->xa = m->rln ? nullptr : take(MH); m->xb = m->rln ? nullptr : take(MH);      // f32 LayerNorm outputs: only without the recomputed residual
         m->ctxH = take_bf(MH); m->factH = take_bf(MF, m->ail); m->xfinalH = take_bf(MH); m->final_in = take(MH);
         const int64_t PM = (int64_t)B * nh * m->Tp * m->Tp;
         const int64_t LS = (int64_t)B * nh * m->Tp;
@@ -373,10 +381,15 @@ static paa_gemm_desc gdb(const paa_model* m, CBf A, CBf W, float* C, Bf Cb, int 
 }
 
 // y = x W^T (+bias) (+epilogue): x (M, K) bf16 planes, W [N][K] bf16 planes
+// A residual that is the LayerNorm of a stored array (gemm.h, res_ln_stats): the post-LN encoder adds LN(x) to its attention / FFN
+// outputs, and the epilogue evaluates it from x and the statistics k_ln_fwd left instead of reading an f32 copy of LN(x)
+struct LnRef { const float* in = nullptr; const float* stats = nullptr; const float* g = nullptr; const float* b = nullptr; };
+
 static paa_status linear(const paa_model* m, CBf x, CBf w, const float* bias, float* y, Bf yb, int M, int N, int K,
                          hipStream_t st, const float* residual = nullptr, int act = 0, float* pre = nullptr,
-                         const float* aux = nullptr, bool x16 = false) {
+                         const float* aux = nullptr, bool x16 = false, const LnRef* rln = nullptr) {
     paa_gemm_desc d = gdb(m, x, w, y, yb, M, N, K, K, K, N);
+    if (rln && rln->in) { residual = rln->in; d.res_ln_stats = rln->stats; d.res_ln_g = rln->g; d.res_ln_b = rln->b; }
     d.bias = bias; d.residual = residual; d.ld_res = N; d.act = act; d.C_pre = pre; d.aux = aux; d.ld_aux = N;
     d.aux_bf16 = x16 ? 1 : 0;
     d.aux_gate = (m->gate && (act == PAA_ACT_GELU || act == PAA_ACT_GELU_GRAD)) ? 1 : 0;     // kept pre-activations hold gelu'(v) (paa_model::pre16)
@@ -435,10 +448,12 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         d.residual = m->h0; d.ld_res = H; d.res_s1 = (int64_t)P * H; d.res_s2 = Hg;
         PAA_TRY(gemm(d, st));
     }
-    const float* x = enc_in;          // f32 hidden state entering the layer
+    const float* x = enc_in;          // f32 hidden state entering the layer (pre-LN variant)
     CBf xH{};                         // its bf16 planes (post-LN variant only)
+    LnRef xln;                        // post-LN variant: the hidden state entering the layer is LN(xln.in), never stored in f32
     if (!a.stable_ln) {
         PAA_TRY(layernorm_fwd(m->hsum, m->enc_ln_g, m->enc_ln_b, m->xa, m->enc_stats, M, H, a.ln_eps, m->xaH, NOBF, nullptr, st));
+        if (m->rln) xln = LnRef{m->hsum, m->enc_stats, m->enc_ln_g, m->enc_ln_b};
         x = m->xa; xH = ro(m->xaH);
     }
     const float scale = 1.0f / sqrtf((float)hd);
@@ -478,12 +493,16 @@ static paa_status forward(paa_model* m, const float* clean, const float* p, int 
         }
         }
         if (!a.stable_ln) {
-            PAA_TRY(linear(m, ctxH, e.wo, e.bo, e.ln1_in, NOBF, M, H, H, st, x));                                // r1 = x + attn
-            PAA_TRY(layernorm_fwd(e.ln1_in, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));   // y1
+            // (m->rln: x / m->xb are null and the residual comes from the LnRef; else the f32 LayerNorm outputs are read back)
+            PAA_TRY(linear(m, ctxH, e.wo, e.bo, e.ln1_in, NOBF, M, H, H, st, x, 0, nullptr, nullptr, false, &xln));       // r1 = LN(x_in) + attn
+            PAA_TRY(layernorm_fwd(e.ln1_in, e.ln1_g, e.ln1_b, m->xb, e.st1, M, H, a.ln_eps, m->xbH, NOBF, nullptr, st));        // y1
+            LnRef y1;
+            if (m->rln) y1 = LnRef{e.ln1_in, e.st1, e.ln1_g, e.ln1_b};
             PAA_TRY(linear(m, ro(m->xbH), e.w1, e.b1, nullptr, m->factH, M, F, H, st, nullptr, PAA_ACT_GELU, e.fpre, nullptr, m->pre16));
-            PAA_TRY(linear(m, ro(m->factH), e.w2, e.b2, e.ln2_in, NOBF, M, H, F, st, m->xb));                   // r2 = y1 + ffn
+            PAA_TRY(linear(m, ro(m->factH), e.w2, e.b2, e.ln2_in, NOBF, M, H, F, st, m->xb, 0, nullptr, nullptr, false, &y1));   // r2 = y1 + ffn
             if (lastl) PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, nullptr, e.st2, M, H, a.ln_eps, m->xfinalH, NOBF, nullptr, st));
             else PAA_TRY(layernorm_fwd(e.ln2_in, e.ln2_g, e.ln2_b, m->xa, e.st2, M, H, a.ln_eps, m->xaH, NOBF, nullptr, st));
+            if (m->rln) xln = LnRef{e.ln2_in, e.st2, e.ln2_g, e.ln2_b};
             x = m->xa; xH = ro(m->xaH);
         } else {
             PAA_TRY(linear(m, ctxH, e.wo, e.bo, e.ln2_in, NOBF, M, H, H, st, x));                                // r1 = x + attn

@@ -5,7 +5,8 @@ device: one model per variant at the headline shape, timed in alternating rounds
     gpurun -- 'PAA_EXTRA_HIPCC_FLAGS=-DPAA_EXPERIMENTS python tools/model_ab.py default no_ail no_c0dma'
 
 Variants: default = the shipped behaviour; no_ail = planar activation planes instead of the interleaved ones (gemm.h A_il / Cb_il;
-read at model creation); no_c0dma = the register-staged conv0 GroupNorm backward instead of the LDS-DMA one (read per launch).
+read at model creation); no_c0dma = the register-staged conv0 GroupNorm backward instead of the LDS-DMA one (read per launch);
+no_rln = f32 LayerNorm outputs written and read back as residuals instead of LN(x) evaluated in the epilogue (gemm.h res_ln_stats).
 """
 import json
 import os
@@ -23,8 +24,8 @@ from paa_amd.training_utils import parser
 from paa_amd.training_utils.pgd import PgdStepper
 
 
-VARIANTS = {"default": {}, "no_ail": {"PAA_NO_AIL": "1"}, "no_c0dma": {"PAA_NO_C0DMA": "1"}}
-SWITCHES = ("PAA_NO_AIL", "PAA_NO_C0DMA")
+VARIANTS = {"default": {}, "no_ail": {"PAA_NO_AIL": "1"}, "no_c0dma": {"PAA_NO_C0DMA": "1"}, "no_rln": {"PAA_NO_RLN": "1"}}
+SWITCHES = ("PAA_NO_AIL", "PAA_NO_C0DMA", "PAA_NO_RLN")
 
 
 def set_env(name):
