@@ -426,7 +426,9 @@ paa_status conv0_dgrad_fused(const Conv0Args& a, float* part, hipStream_t st) {
     Conv0Args b = a;
     b.part = part;
     int nblk = conv0_dgrad_blocks(a.B, a.T);
-    bool dma = a.C == DG_CMAX;
+    // (split mode only: with one plane the register-staged form keeps two workgroups per CU without spilling and measures 272 us
+    // against 294 for the DMA form)
+    bool dma = a.C == DG_CMAX && a.dpreb.lo != nullptr;
 #ifdef PAA_EXPERIMENTS      // tools/model_ab.py: the register-staged form
     { const char* e = getenv("PAA_NO_C0DMA"); if (e && e[0] == '1') dma = false; }
 #endif

@@ -279,12 +279,15 @@ __global__ __launch_bounds__(256) void k_conv0_gn(Conv0Args a) {
                             *reinterpret_cast<float2*>(a.pre + o) = make_float2(y.x, y.y);
                         }
                         const unsigned short h0 = bf16_bits(g.x), h1 = bf16_bits(g.y);
-                        // (o is even: the channel pair stays inside one 32-element group of the interleaved form, paa_common.h Bf::il)
-                        unsigned short* ph = a.actb.il ? a.actb.hi + il_index(o) : a.actb.hi + o;
-                        unsigned short* pl = a.actb.il ? ph + 32 : (a.actb.lo ? a.actb.lo + o : nullptr);
-                        *reinterpret_cast<unsigned*>(ph) = h0 | ((unsigned)h1 << 16);
-                        if (pl)
-                            *reinterpret_cast<unsigned*>(pl) = bf16_bits(g.x - bf16_to_f32(h0)) | ((unsigned)bf16_bits(g.y - bf16_to_f32(h1)) << 16);
+                        if (a.actb.il) {     // (o is even: the channel pair stays inside one 32-element group, paa_common.h Bf::il)
+                            unsigned short* ph = a.actb.hi + il_index(o);
+                            *reinterpret_cast<unsigned*>(ph) = h0 | ((unsigned)h1 << 16);
+                            *reinterpret_cast<unsigned*>(ph + 32) = bf16_bits(g.x - bf16_to_f32(h0)) | ((unsigned)bf16_bits(g.y - bf16_to_f32(h1)) << 16);
+                        } else {
+                            *reinterpret_cast<unsigned*>(a.actb.hi + o) = h0 | ((unsigned)h1 << 16);
+                            if (a.actb.lo)
+                                *reinterpret_cast<unsigned*>(a.actb.lo + o) = bf16_bits(g.x - bf16_to_f32(h0)) | ((unsigned)bf16_bits(g.y - bf16_to_f32(h1)) << 16);
+                        }
                     } else {
                         const f32x2 dy = {__uint_as_float(dh[f] << 16) + __uint_as_float(dl4[f] << 16),
                                           __uint_as_float(dh[f] & 0xFFFF0000u) + __uint_as_float(dl4[f] & 0xFFFF0000u)};
