@@ -29,18 +29,6 @@ constexpr int DG_T = 32;                 // frames per tile
 constexpr int DG_CMAX = 512;             // channels (multiple of 32)
 constexpr int DG_RS = DG_CMAX + 8;       // LDS row stride of the tile in bf16 (16-byte aligned rows, 4-bank skew)
 
-static int device_cus_conv0() {          // compute units of the current device (cached per device id)
-    static int cache[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!cache[dev]) {
-        int c = 0;
-        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
-        cache[dev] = c;
-    }
-    return cache[dev];
-}
-
 int conv0_dgrad_blocks(int B, int T) {
     const int ntiles = cdiv(T, DG_T);
     return std::max(1, std::min(std::min(512 / std::max(B, 1), 64), ntiles));
@@ -435,7 +423,7 @@ paa_status conv0_dgrad_fused(const Conv0Args& a, float* part, hipStream_t st) {
     if (dma) {
         // LDS-DMA form: one workgroup per CU (double-buffered tile), so half as many workgroups per clip cover the chip
         const int ntiles = cdiv(a.T, DG_T);
-        nblk = std::max(1, std::min(std::min(device_cus_conv0() / std::max(a.B, 1), 64), ntiles));
+        nblk = std::max(1, std::min(std::min(device_cus() / std::max(a.B, 1), 64), ntiles));
         const int npl = a.dpreb.lo ? 2 : 1;
         constexpr int NWV = 8;
         const size_t lds = 2 * (size_t)npl * DG_T * DG_RS * 2 + NWV * DG_T * 16 * 4 + 2 * ((DG_T - 1) * 5 + 10 + 1) * 4;

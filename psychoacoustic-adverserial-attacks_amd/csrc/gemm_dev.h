@@ -18,19 +18,7 @@ struct GemmArgs {
 };
 
 // ---- persistent-grid sizing (host) ----------------------------------------------------------------
-// Compute units of the CURRENT device, cached per device id (a process may drive several devices, and a partitioned part
-// reports fewer CUs than the 256 of a whole MI355X).
-inline int device_cus() {
-    static int cache[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!cache[dev]) {
-        int c = 0;
-        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
-        cache[dev] = c;
-    }
-    return cache[dev];
-}
+// (device_cus(): paa_common.h)
 // Workgroups of `kernel` one CU holds: a property of the code object (registers, LDS), equal on every gfx950 device, so a
 // per-kernel static may cache it; the grid is this times device_cus() of the device in use.
 template <typename K>

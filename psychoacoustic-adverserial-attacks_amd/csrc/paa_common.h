@@ -40,6 +40,20 @@ void set_error(const std::string& msg);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Compute units of the CURRENT device, cached per device id (a process may drive several devices, and a partitioned part
+// reports fewer CUs than the 256 of a whole MI355X).
+inline int device_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cache[dev]) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cache[dev] = c;
+    }
+    return cache[dev];
+}
+
 // ---- wave (64 lanes) / block reductions --------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

@@ -149,36 +149,40 @@ __device__ __forceinline__ float2 bin_op(float2 v, int k, const BinCtx& c, float
     return v;
 }
 
+// Raw samples of frame t of one row: raw[n2] = (x[2m], x[2m + 1]), m = lane + 64 n2 (center=True: reflect pad 512).
+__device__ __forceinline__ void frame_load(const SpecArgs& a, const float* __restrict__ xr, int t, int lane, float2 (&raw)[8]) {
+    const int s0 = t * HOP - N2;                              // first sample of the frame
+    const bool inside = s0 >= 0 && s0 + N <= a.L && ((a.L & 1) == 0);
+    if (inside) {
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) raw[n2] = *reinterpret_cast<const float2*>(xr + s0 + 2 * (lane + 64 * n2));
+    } else {
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) {
+            int i0 = s0 + 2 * (lane + 64 * n2), i1 = i0 + 1;
+            if (i0 < 0) i0 = -i0;
+            if (i0 >= a.L) i0 = 2 * (a.L - 1) - i0;
+            if (i1 < 0) i1 = -i1;
+            if (i1 >= a.L) i1 = 2 * (a.L - 1) - i1;
+            raw[n2] = make_float2(xr[i0], xr[i1]);
+        }
+    }
+}
+
 // One frame, start to end, by one wave.
 //   SRC_SPEC: the spectrum comes from S_in (iSTFT) instead of the waveform;  DST_SPEC: stop after the forward transform and
 //   write the spectrum (STFT).  Otherwise the windowed inverse frame is left in xb as 1024 floats.
+//   raw: the frame's samples as frame_load leaves them (unused with SRC_SPEC).
 // Returns this lane's share of sum |S|^2 w (FM).
 template <int OP, bool SRC_SPEC, bool DST_SPEC>
-__device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, const LaneTw& tw, float2* xb, int row, int t, int lane) {
+__device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, const LaneTw& tw, float2* xb, int row, int t, int lane,
+                                            const float2 (&raw)[8]) {
     float2 x[8];
     float2 Xk[4], Xm[4], X0 = make_float2(0.f, 0.f), XN = make_float2(0.f, 0.f);      // bins k = 1 + lane + 64 j, mirrors 512 - k, DC, Nyquist
     float wsum = 0.f;
     if (!SRC_SPEC) {
-        const float* xr = a.x + (size_t)row * a.L;
-        const int s0 = t * HOP - N2;                          // first sample of the frame (center=True: reflect pad 512)
-        const bool inside = s0 >= 0 && s0 + N <= a.L && ((a.L & 1) == 0);
-        if (inside) {
 #pragma unroll
-            for (int n2 = 0; n2 < 8; ++n2) {
-                const float2 v = *reinterpret_cast<const float2*>(xr + s0 + 2 * (lane + 64 * n2));
-                x[n2] = make_float2(v.x * tw.w[n2].x, v.y * tw.w[n2].y);
-            }
-        } else {
-#pragma unroll
-            for (int n2 = 0; n2 < 8; ++n2) {
-                int i0 = s0 + 2 * (lane + 64 * n2), i1 = i0 + 1;
-                if (i0 < 0) i0 = -i0;
-                if (i0 >= a.L) i0 = 2 * (a.L - 1) - i0;
-                if (i1 < 0) i1 = -i1;
-                if (i1 >= a.L) i1 = 2 * (a.L - 1) - i1;
-                x[n2] = make_float2(xr[i0] * tw.w[n2].x, xr[i1] * tw.w[n2].y);
-            }
-        }
+        for (int n2 = 0; n2 < 8; ++n2) x[n2] = make_float2(raw[n2].x * tw.w[n2].x, raw[n2].y * tw.w[n2].y);
         wave_fft512<-1>(x, xb, tw, lane);
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = x[k2];                   // Z in natural order
@@ -297,7 +301,9 @@ __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
             const int f = q * NW + wave;                      // frame slot inside the workgroup
             const int t = c0 - 3 + f;                         // frame index of the row
             if (t >= 0 && t < a.T) {
-                const float ws = wave_frame<OP, SRC_SPEC, false>(a, c, tw, xb, row, t, lane);
+                float2 raw[8];
+                if (!SRC_SPEC) frame_load(a, a.x + (size_t)row * a.L, t, lane, raw);
+                const float ws = wave_frame<OP, SRC_SPEC, false>(a, c, tw, xb, row, t, lane, raw);
                 if (f >= 3 || g == 0) wsum += ws;             // halo frames belong to the previous workgroup's sum
             } else {
 #pragma unroll
@@ -366,6 +372,125 @@ __global__ __launch_bounds__(NW * 64) void k_spec_fused(SpecArgs a) {
         for (int m = valid_len + tid; m < a.out_len; m += NW * 64) outr[m] = 0.f;
 }
 
+// Batched shapes: a workgroup of NW waves walks a RUN of consecutive output hop-blocks [J0, J1) of one row, NW frames per
+// iteration (one per wave), instead of one (NW x FPW)-frame slab per launch slot:
+//  * the three windowed frames a run's next blocks still need stay in LDS (carry) — the 3-frame halo is recomputed once per
+//    RUN (3 of ~80 frames at (32, 160000): 8 runs per row), not once per 24 frames;
+//  * twiddles / window / the FM table are loaded once per run, and the next frame's samples are requested before the
+//    barrier that ends the current iteration, so their latency hides under the overlap-add and the barrier skew;
+//  * wave w's frame t = J0 - 3 + it NW + w is the NEWEST frame of output block j = t, so after the barrier each wave
+//    overlap-adds "its" block from its own result and the three slots before it: four ds_read_b128 and one 16-byte store per lane.
+// grid: (runs per row, rows), bpr = blocks per run.
+template <int OP, int NW>
+__global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
+    extern __shared__ __attribute__((aligned(16))) float2 xbuf[];                   // [NW][XB] exchange / result | [3][512] carry | small arrays
+    constexpr int TAIL = NW * XB + 3 * N2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x, row = blockIdx.y;
+    const int J0 = 2 + g * bpr, JE = 1 + a.T;                 // output blocks of the row: 2 .. T (padded-signal block index)
+    const int J1 = J0 + bpr < JE ? J0 + bpr : JE;
+    if (J0 >= J1) {                                           // an empty run at the end of the row (uniform for the workgroup)
+        if (OP == SOP_FM && tid == 0) a.part[(size_t)row * gridDim.x + g] = 0.0;
+        return;
+    }
+    float2* xb = xbuf + wave * XB;
+    float* carry = reinterpret_cast<float*>(xbuf + NW * XB);  // [3][1024]: frame slots NW-3 .. NW-1 of the previous iteration
+    BinCtx c;
+    c.fm = a.fm; c.thr = a.thr; c.thr_off = a.phon_ref - (OP == SOP_PHON ? a.thr_max[0] : 0.f);
+    c.bin_hz = a.bin_hz; c.min_f = a.min_f; c.max_f = a.max_f;
+    if (OP == SOP_FM) {
+        float* fml = reinterpret_cast<float*>(xbuf + TAIL) + 64;
+        for (int i = tid; i < 10 * F; i += NW * 64) fml[i] = a.fm[i];
+        c.fm = fml;
+        __syncthreads();
+    }
+    const int niter = (J1 - J0 + 3 + NW - 1) / NW;
+    const int t_end = J1 < a.T ? J1 : a.T;                    // frames this run needs: [J0 - 3, t_end) (block j needs frames j-3 .. j)
+    const float* xr = a.x + (size_t)row * a.L;
+    float* outr = a.out + (size_t)row * a.out_len;
+    const bool vec_ok = ((a.out_len & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+    LaneTw tw;
+    lane_tw(tw, a.tw, a.win, lane);
+    float2 raw[8];
+    int t = J0 - 3 + wave;
+    if (t >= 0 && t < t_end) frame_load(a, xr, t, lane, raw);
+    float wsum = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < niter; ++it, t += NW) {
+        if (t >= 0 && t < t_end) {
+            const float ws = wave_frame<OP, false, false>(a, c, tw, xb, row, t, lane, raw);
+            if (t >= J0 || g == 0) wsum += ws;                // halo frames belong to the previous run's sum
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(0.f, 0.f);
+        }
+        if (it + 1 < niter && t + NW >= 0 && t + NW < t_end) frame_load(a, xr, t + NW, lane, raw);
+        __syncthreads();                                      // this iteration's frames are in LDS
+        if (t >= J0 && t < J1) {                              // block j = t <- frames t-3 .. t = slots wave-3 .. wave at offsets 768, 512, 256, 0
+            const int j = t;
+            const float* fq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sl = wave - 3 + q;
+                fq[q] = (sl >= 0 ? reinterpret_cast<const float*>(xbuf + sl * XB) : carry + (3 + sl) * N) + HOP * (3 - q);
+            }
+            float* o = outr + (size_t)HOP * (j - 2);
+            if (j >= 3 && j < a.T) {
+                // interior: all four frames exist; the periodic Hann window's squared overlap-add is exactly 3/2
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(fq[q] + 4 * lane);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                const float s = 0.666666686534881591796875f;
+                acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
+                if (vec_ok) *reinterpret_cast<float4*>(o + 4 * lane) = acc;
+                else { o[4 * lane] = acc.x; o[4 * lane + 1] = acc.y; o[4 * lane + 2] = acc.z; o[4 * lane + 3] = acc.w; }
+            } else {
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * lane + e;
+                    float sum = 0.f, env = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int tq = j - 3 + q;
+                        if (tq >= 0 && tq < a.T) {
+                            sum += fq[q][r];
+                            const float w = a.win[HOP * (3 - q) + r];
+                            env += w * w;
+                        }
+                    }
+                    o[r] = sum / env;
+                }
+            }
+        }
+        __syncthreads();                                      // every block of the iteration is out: results may be overwritten
+        if (wave >= NW - 3 && it + 1 < niter) {               // the next iteration's blocks reach back three frames
+            const float4* src = reinterpret_cast<const float4*>(xb);
+            float4* dst = reinterpret_cast<float4*>(carry + (wave - (NW - 3)) * N);
+            const float4 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
+            dst[lane] = v0; dst[lane + 64] = v1; dst[lane + 128] = v2; dst[lane + 192] = v3;
+        }
+    }
+    if (OP == SOP_FM) {
+        const double dsum = wave_sum((double)wsum);
+        double* red = reinterpret_cast<double*>(xbuf + TAIL);
+        if (lane == 0) red[wave] = dsum;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int w = 0; w < NW; ++w) s += red[w];
+            a.part[(size_t)row * gridDim.x + g] = s;
+        }
+    }
+    // _align_to (train.py:27-35): samples past the iSTFT length are zero; the run that ends the row writes them
+    if (J1 == JE) {
+        const int valid_len = HOP * (a.T - 1);
+        for (int m = valid_len + tid; m < a.out_len; m += NW * 64) outr[m] = 0.f;
+    }
+}
+
 // STFT only: one wave per frame, 4 frames per workgroup.  grid: (ceil(T / 4), rows)
 __global__ __launch_bounds__(256) void k_spec_stft(SpecArgs a) {
     __shared__ __attribute__((aligned(16))) float2 xbuf[4 * XB];
@@ -376,7 +501,9 @@ __global__ __launch_bounds__(256) void k_spec_stft(SpecArgs a) {
     LaneTw tw;
     lane_tw(tw, a.tw, a.win, lane);
     BinCtx c{};
-    wave_frame<SOP_NONE, false, true>(a, c, tw, xbuf + wave * XB, row, t, lane);
+    float2 raw[8];
+    frame_load(a, a.x + (size_t)row * a.L, t, lane, raw);
+    wave_frame<SOP_NONE, false, true>(a, c, tw, xbuf + wave * XB, row, t, lane, raw);
 }
 
 // per-bin op on a spectrum in memory (frame-major (rows, T, F) complex64), optional uniform scale
@@ -403,21 +530,34 @@ __global__ __launch_bounds__(256) void k_spec_apply(SpecArgs a, int64_t n, const
     }
 }
 
-// Frames per workgroup.  Single rows / small batches: 8 waves x 1 frame (5 / 8 of the FFTs useful, two workgroups per CU).  Batches
-// (>= 256 workgroups of 13 blocks): 12 waves x 2 frames (21 / 24 useful) — round 2 ran 16 x 1 there (13 / 16 useful).  Measured and not kept: 4 x 1 at (1, 160000): 10.2 vs 9.1 us;
-// 12 x 1 at two workgroups per CU on the batch: 84 vs 79 us (both still selectable through PAA_SPEC_NW in -DPAA_EXPERIMENTS builds).
-struct SpecGeom { int nw, fpw; };
+// Launch geometry.  Single rows / small batches: 8 waves x 1 frame per workgroup (5 / 8 of the FFTs useful, two workgroups per CU,
+// one round — latency is what counts there).  Batches: runs of consecutive blocks walked by 12-wave workgroups (k_spec_run; round 3
+// ran 12 x 2-frame slabs there, 21 / 24 of the FFTs useful and every slab paying its own launch slot, twiddle loads and exposed
+// sample loads).  Measured and not kept: 4 x 1 at (1, 160000): 10.2 vs 9.1 us; 12 x 1 at two workgroups per CU on the batch: 84 vs 79 us.
+constexpr int RUN_NW = 12;                  // 3 waves per SIMD at <= 170 registers; 16 would need <= 128 and spills
+struct SpecGeom { int nw, fpw, runs; };     // runs > 0: k_spec_run<OP, RUN_NW> with that many runs per row
 static SpecGeom spec_geom(int T, int rows, int op, bool src_spec) {
 #ifdef PAA_EXPERIMENTS
     static const int force = [] { const char* e = getenv("PAA_SPEC_NW"); return e ? atoi(e) : 0; }();
     static const int force_fpw = [] { const char* e = getenv("PAA_SPEC_FPW"); return e ? atoi(e) : 1; }();
     if (force == 4 || force == 8 || force == 12 || force == 16)
-        return SpecGeom{force, (force_fpw == 2 && !src_spec && (force == 12 || force == 16)) ? 2 : 1};
+        return SpecGeom{force, (force_fpw == 2 && !src_spec && (force == 12 || force == 16)) ? 2 : 1, 0};
 #endif
-    if (rows * cdiv(T - 1, 13) < 256) return SpecGeom{8, 1};
-    if (src_spec) return SpecGeom{16, 1};
     (void)op;
-    return SpecGeom{12, 2};     // 16 x 2 would recompute less halo (3 of 32) but its 128-register budget spills 9..15 registers per lane
+    const int nblk = T - 1;
+    if (rows * cdiv(nblk, 13) < 256) return SpecGeom{8, 1, 0};
+    if (src_spec) return SpecGeom{16, 1, 0};
+    // runs per row: one workgroup per CU and round; a run of b blocks costs ceil((b + 3) / NW) iterations plus its start-up
+    // (twiddles, first samples: about half an iteration).  Pick the count with the least (rounds x run time).
+    const int cus = device_cus();
+    int best = 1;
+    double best_cost = 1e30;
+    for (int r = 1; r <= cdiv(nblk, RUN_NW - 3); ++r) {
+        const int b = cdiv(nblk, r);
+        const double cost = (double)cdiv((int64_t)rows * r, cus) * (cdiv(b + 3, RUN_NW) + 0.5);
+        if (cost < best_cost) { best_cost = cost; best = r; }
+    }
+    return SpecGeom{RUN_NW, 1, best};
 }
 
 template <int OP, bool SRC_SPEC, int NW, int FPW>
@@ -434,16 +574,28 @@ paa_status launch_fused_nw(const SpecArgs& a, int rows, hipStream_t st) {
     return PAA_OK;
 }
 
+template <int OP>
+paa_status launch_run(const SpecArgs& a, int rows, int runs, hipStream_t st) {
+    constexpr int NW = RUN_NW;
+    const size_t lds = sizeof(float2) * (NW * XB + 3 * N2) + 256 + (OP == SOP_FM ? sizeof(float) * 10 * F : 0);
+    static bool attr = false;                                 // > 64 KB of dynamic LDS needs the attribute (per code object: set once)
+    if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spec_run<OP, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((k_spec_run<OP, NW>), dim3(runs, rows), dim3(NW * 64), lds, st, a, cdiv(a.T - 1, runs));
+    PAA_LAUNCH_CHECK();
+    return PAA_OK;
+}
+
 template <int OP, bool SRC_SPEC>
 paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
     const SpecGeom gm = spec_geom(a.T, rows, OP, SRC_SPEC);
-    if (gm.fpw == 2) {
-        if constexpr (!SRC_SPEC) {
+    if constexpr (!SRC_SPEC && OP != SOP_NONE) {
+        if (gm.runs > 0) return launch_run<OP>(a, rows, gm.runs, st);
 #ifdef PAA_EXPERIMENTS
+        if (gm.fpw == 2) {
             if (gm.nw == 16 && OP != SOP_FM) return launch_fused_nw<OP, SRC_SPEC, 16, 2>(a, rows, st);
-#endif
             return launch_fused_nw<OP, SRC_SPEC, 12, 2>(a, rows, st);
         }
+#endif
     }
     switch (gm.nw) {
         case 16: return launch_fused_nw<OP, SRC_SPEC, 16, 1>(a, rows, st);
@@ -459,7 +611,7 @@ paa_status launch_fused(const SpecArgs& a, int rows, hipStream_t st) {
 
 int spec_groups(int T, int rows, int op, bool src_spec) {
     const SpecGeom gm = spec_geom(T, rows, op, src_spec);
-    return cdiv(T - 1, gm.nw * gm.fpw - 3);
+    return gm.runs > 0 ? gm.runs : cdiv(T - 1, gm.nw * gm.fpw - 3);
 }
 
 paa_status spec_project(const SpecArgs& a, int op, int rows, int* n_part, hipStream_t st) {

@@ -175,10 +175,60 @@ def test_out_of_place_equals_in_place_and_batched_rows():
             b = torch.empty_like(src)
             _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(src), _lib.ptr(b), rows, None, 0, L, _lib.stream_ptr()))
             assert torch.equal(a, b), (norm, rows)
-        if norm != "fletcher_munson":          # row 0 of the batch (16-frame workgroups) == the single row (8-frame workgroups)
+        if norm != "fletcher_munson":          # row 0 of the batch (run kernel) against the single row (slab kernel): the same arithmetic
+            # up to where the compiler forms fmas in the two kernels (measured 1.7e-7 of the peak)
             one = torch.empty(1, L, device="cuda"); many = torch.empty(32, L, device="cuda")
             _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(x[:1].contiguous()), _lib.ptr(one), 1, None, 0, L, _lib.stream_ptr()))
             _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(x), _lib.ptr(many), 32, None, 0, L, _lib.stream_ptr()))
-            assert torch.equal(one[0], many[0]), norm
+            assert float((one[0] - many[0]).abs().max()) <= 1e-6 * float(one.abs().max()), norm
         with pytest.raises(Exception):
             _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(x), _lib.ptr(x), 32, None, 0, L, _lib.stream_ptr()))
+
+
+@pytest.mark.parametrize("rows,L", [(32, 160000), (24, 40001), (9, 480000), (40, 33000)])
+def test_run_kernel_rows_vs_single_row_kernel_and_oracle(rows, L):
+    """Batched shapes go through the run-walking kernel (k_spec_run: carried frames, prefetched samples, per-wave
+    overlap-add); a single row goes through the slab kernel (k_spec_fused, 8 frames).  Same per-frame arithmetic and the
+    same overlap-add order — the two differ only where the compiler contracts a product and a sum into an fma (measured
+    1.7e-7 of the peak), so every checked row of the batch must equal that row projected alone to 1e-6 of the peak, and the
+    oracle to TOL: odd L (reflect path on every frame, scalar stores), L not a multiple of the hop (zero tail), 30 s rows
+    (11 iterations per run), more rows than a round of workgroups."""
+    from paa_amd import _lib, runtime
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(rows * 1000003 + L)
+    x = (torch.randn(rows, L, generator=g) * 0.05)
+    xc = x.cuda()
+    for norm, extra in (("min_max_freqs", []), ("max_phon", []), ("fletcher_munson", ["--fm_epsilon", "0.5"])):
+        args = _args(norm, extra)
+        spl = build.init_phon_threshold_tensor(args)
+        pr = runtime.get_proj(args, xc.device, rows, L)
+        pr.set_spl_thresh(spl)
+        prm = runtime.params_of(args)
+        many = torch.full((rows, L), float("nan"), device="cuda")
+        _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(xc), _lib.ptr(many), rows, None, 0, L, _lib.stream_ptr()))
+        assert bool(torch.isfinite(many).all()), norm
+        picked = sorted({0, 1, rows // 2, rows - 1})
+        for r in picked:
+            one = torch.full((1, L), float("nan"), device="cuda")
+            _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(xc[r:r + 1].contiguous()), _lib.ptr(one), 1, None, 0, L, _lib.stream_ptr()))
+            if norm != "fletcher_munson":
+                d = float((one[0] - many[r]).abs().max())
+                assert d <= 1e-6 * float(one.abs().max()), (norm, r, d)
+        if norm == "fletcher_munson":
+            # ONE factor for the whole tensor (projections.py:115-133): the oracle on the whole batch would take minutes at 30 s, so
+            # check that factor row against row through the STFT -> iSTFT identity (many = s x on the iSTFT's support) ...
+            V = 256 * (L // 256)                      # iSTFT length; the tail behind it is zero-filled
+            ratio = many[0, :V].double().norm() / xc[0, :V].double().norm()
+            for r in (1, rows - 1):
+                rr = many[r, :V].double().norm() / xc[r, :V].double().norm()
+                assert abs(float(rr / ratio) - 1.0) < 1e-5, (r, float(rr), float(ratio))
+            if L > 200000:
+                continue
+            # ... and the factor itself against the oracle on the whole batch
+            ref = OP.perturbation_constraint(x, x, args, OP.spl_thresh_tensor(args)).numpy()
+            assert rel_err(many.cpu().numpy(), ref) <= TOL, norm
+        else:
+            # per-row ops: the oracle on the picked rows alone
+            sel = x[picked]
+            ref = OP.perturbation_constraint(sel, sel, args, OP.spl_thresh_tensor(args)).numpy()
+            assert rel_err(many[picked].cpu().numpy(), ref) <= TOL, norm
