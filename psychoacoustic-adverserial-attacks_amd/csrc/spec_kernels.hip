@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "spec_kernels.h"
+#include "spec_pk.h"
 
 namespace paa {
 
@@ -29,68 +30,47 @@ namespace {
 constexpr int XB = 640;                 // complex slots of one wave's exchange buffer (5120 B)
 constexpr int N = 1024, N2 = 512, HOP = 256, F = 513;
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-// v * (S i): S = -1 forward, +1 inverse
-template <int S>
-__device__ __forceinline__ float2 muli(float2 v) { return S > 0 ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x); }
-
-// 8-point DFT in registers, e^{S 2 pi i nk / 8}
-template <int S>
-__device__ __forceinline__ void dft8(float2 (&x)[8]) {
-    const float r = 0.70710678118654752f;
-    const float2 a0 = cadd(x[0], x[4]), a1 = csub(x[0], x[4]), a2 = cadd(x[2], x[6]), a3 = csub(x[2], x[6]);
-    const float2 a4 = cadd(x[1], x[5]), a5 = csub(x[1], x[5]), a6 = cadd(x[3], x[7]), a7 = csub(x[3], x[7]);
-    const float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, muli<S>(a3)), b3 = csub(a1, muli<S>(a3));
-    const float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, muli<S>(a7)), b7 = csub(a5, muli<S>(a7));
-    x[0] = cadd(b0, b4); x[4] = csub(b0, b4);
-    x[2] = cadd(b2, muli<S>(b6)); x[6] = csub(b2, muli<S>(b6));
-    const float2 t1 = make_float2(r * (b5.x - S * b5.y), r * (b5.y + S * b5.x));      // b5 (1 + S i) / sqrt 2
-    x[1] = cadd(b1, t1); x[5] = csub(b1, t1);
-    const float2 t3 = make_float2(r * (-b7.x - S * b7.y), r * (-b7.y + S * b7.x));    // b7 (-1 + S i) / sqrt 2
-    x[3] = cadd(b3, t3); x[7] = csub(b3, t3);
-}
-
 // per-lane constants of the wave FFT (lane = a = 8 n1 + n0 in the first pass)
 struct LaneTw {
-    float2 a[7];      // W512^(lane k0), k0 = 1..7
-    float2 b[7];      // W64^((lane & 7) k1), k1 = 1..7
-    float2 p[4];      // e^{-2 pi i k / 1024}, k = 1 + lane + 64 j
-    float2 w[8];      // window at samples 2m, 2m + 1, m = lane + 64 n2
+    v2f a[7];       // W512^(lane k0), k0 = 1..7
+    v2f b[7];       // W64^((lane & 7) k1), k1 = 1..7
+    v2f pm[4];      // (-i / 2) e^{-2 pi i k / 1024}, k = 1 + lane + 64 j: the split post-pass's factor; the inverse pre-pass uses 2 conj(pm) = i conj(p)
+    v2f w[8];       // window at samples 2m, 2m + 1, m = lane + 64 n2
 };
 __device__ __forceinline__ void lane_tw(LaneTw& t, const float2* __restrict__ tw, const float* __restrict__ win, int lane) {
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
-        t.a[k - 1] = tw[(2 * lane * k) & 1023];
-        t.b[k - 1] = tw[(16 * (lane & 7) * k) & 1023];
+        t.a[k - 1] = pk_v(tw[(2 * lane * k) & 1023]);
+        t.b[k - 1] = pk_v(tw[(16 * (lane & 7) * k) & 1023]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t.p[j] = tw[1 + lane + 64 * j];
+    for (int j = 0; j < 4; ++j) {
+        const float2 p = tw[1 + lane + 64 * j];
+        t.pm[j] = v2f{0.5f * p.y, -0.5f * p.x};
+    }
 #pragma unroll
-    for (int n2 = 0; n2 < 8; ++n2) t.w[n2] = *reinterpret_cast<const float2*>(win + 2 * (lane + 64 * n2));
+    for (int n2 = 0; n2 < 8; ++n2) t.w[n2] = pk_v(*reinterpret_cast<const float2*>(win + 2 * (lane + 64 * n2)));
 }
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+// Workgroup barrier that orders LDS only: __syncthreads() also drains vmcnt, i.e. it would wait for the NEXT frame's samples
+// (requested just before it) and for the overlap-add's global stores — a full memory round trip per iteration on the critical path.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // 512-point complex FFT of one wave.  In: x[n2] = z[64 n2 + lane].  Out: x[k2] = Z[lane + 64 k2].
-// S = -1: forward; S = +1: unnormalised inverse.  xb: this wave's exchange buffer.
+// S = -1: forward; S = +1: unnormalised inverse.  xb: this wave's exchange buffer (second exchange only).  3 x 26 + 14 x 2 packed
+// instructions + the register transpose.
 template <int S>
-__device__ __forceinline__ void wave_fft512(float2 (&x)[8], float2* xb, const LaneTw& t, int lane) {
-    dft8<S>(x);
+__device__ __forceinline__ void wave_fft512(v2f (&x)[8], v2f* xb, const LaneTw& t, int lane) {
+    pk_dft8<S>(x);
 #pragma unroll
-    for (int k = 1; k < 8; ++k) x[k] = cmulf(x[k], S < 0 ? t.a[k - 1] : cconj(t.a[k - 1]));
-#pragma unroll
-    for (int k = 0; k < 8; ++k) xb[k * 72 + lane] = x[k];                          // E1[k0][a], rows of 72
-    wave_fence();
+    for (int k = 1; k < 8; ++k) x[k] = S < 0 ? pk_cmul(x[k], t.a[k - 1]) : pk_cmul_conj(x[k], t.a[k - 1]);
+    // E1[k0][a = 8 n1 + n0] -> lane (k0, n0), register n1: register index against lane bits 5:3, in registers (spec_pk.h)
+    pk_transpose_hi(x);
     const int k0 = lane >> 3, n0 = lane & 7;
+    pk_dft8<S>(x);
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) x[n1] = xb[k0 * 72 + 8 * n1 + n0];
-    wave_fence();
-    dft8<S>(x);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) x[k] = cmulf(x[k], S < 0 ? t.b[k - 1] : cconj(t.b[k - 1]));
+    for (int k = 1; k < 8; ++k) x[k] = S < 0 ? pk_cmul(x[k], t.b[k - 1]) : pk_cmul_conj(x[k], t.b[k - 1]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) xb[(k0 + 8 * k1) * 10 + n0] = x[k1];             // E2[t = k0 + 8 k1][n0], rows of 10
     wave_fence();
@@ -99,12 +79,12 @@ __device__ __forceinline__ void wave_fft512(float2 (&x)[8], float2* xb, const La
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v = r[q];
-            x[2 * q] = make_float2(v.x, v.y);
-            x[2 * q + 1] = make_float2(v.z, v.w);
+            x[2 * q] = v2f{v.x, v.y};
+            x[2 * q + 1] = v2f{v.z, v.w};
         }
     }
     wave_fence();
-    dft8<S>(x);
+    pk_dft8<S>(x);
 }
 
 struct BinCtx {
@@ -121,18 +101,21 @@ __device__ __forceinline__ float2 bin_op(float2 v, int k, const BinCtx& c, float
         return make_float2(v.x * m, v.y * m);
     } else if (OP == SOP_PHON) {                 // projections.py:138-159
         // log10 / exp10 through the hardware log2 / exp2 (arguments are normal and far from overflow here): the absolute
-        // error of 20 log10(.) stays at the rounding of its own result (~1e-6 dB), as with libm's log10f
-        const float mag = sqrtf(v.x * v.x + v.y * v.y);
+        // error of 20 log10(.) stays at the rounding of its own result (~1e-6 dB), as with libm's log10f.  |S| and 1 / |S| both
+        // come from ONE v_rsq_f32 of |S|^2 (1 ulp; the correctly rounded sqrtf + division they replace were ~25 issue slots per bin).
+        const float pw = v.x * v.x + v.y * v.y;
+        const bool nz = pw > 1e-30f;             // below: |S| < 1e-15 acts as 0 (the reference would keep its phase on a 1e-8 magnitude)
+        const float rs = __builtin_amdgcn_rsqf(nz ? pw : 1.f);
+        const float mag = nz ? pw * rs : 0.f;
         const float mag_db = 6.02059991327962390f * __builtin_amdgcn_logf(mag + 1e-8f);            // 20 log10(2) log2(x)
         const float thr = c.thr[k] + c.thr_off;
         const float db = (mag_db > thr) ? thr : mag_db;
         const float mc = __builtin_amdgcn_exp2f(db * 0.166096404744368118f);                          // 10^(db / 20)
         // mc e^{i angle(S)}: S / |S| is that unit phasor; angle(0) = 0
-        if (mag > 0.f) { const float s = mc / mag; return make_float2(v.x * s, v.y * s); }
-        return make_float2(mc, 0.f);
+        const float sc = mc * rs;
+        return nz ? make_float2(v.x * sc, v.y * sc) : make_float2(mc, 0.f);
     } else if (OP == SOP_FM) {                   // projections.py:83-113: bilinear iso-grid weight at (10 log10(|S|^2 + 1e-10), f_bin)
-        const float mag = sqrtf(v.x * v.x + v.y * v.y);
-        const float pw = mag * mag;
+        const float pw = v.x * v.x + v.y * v.y;  // abs() ** 2 without the round trip through the square root
         const float s = 3.01029995663981195f * __builtin_amdgcn_logf(pw + 1e-10f);                   // 10 log10(x) via log2
         float w = 1.f;
         const float w0 = c.fm[k];
@@ -175,14 +158,17 @@ __device__ __forceinline__ void frame_load(const SpecArgs& a, const float* __res
 //   raw: the frame's samples as frame_load leaves them (unused with SRC_SPEC).
 // Returns this lane's share of sum |S|^2 w (FM).
 template <int OP, bool SRC_SPEC, bool DST_SPEC>
-__device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, const LaneTw& tw, float2* xb, int row, int t, int lane,
+__device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, const LaneTw& tw, float2* xbf, int row, int t, int lane,
                                             const float2 (&raw)[8]) {
-    float2 x[8];
-    float2 Xk[4], Xm[4], X0 = make_float2(0.f, 0.f), XN = make_float2(0.f, 0.f);      // bins k = 1 + lane + 64 j, mirrors 512 - k, DC, Nyquist
+    v2f* xb = reinterpret_cast<v2f*>(xbf);
+    v2f x[8];
+    v2f Xk[4], Xm[4];                                         // bins k = 1 + lane + 64 j and their mirrors 512 - k
+    float2 X0 = make_float2(0.f, 0.f), XN = make_float2(0.f, 0.f);      // DC, Nyquist
     float wsum = 0.f;
+    const v2f half = {0.5f, 0.5f}, two = {2.f, 2.f};
     if (!SRC_SPEC) {
 #pragma unroll
-        for (int n2 = 0; n2 < 8; ++n2) x[n2] = make_float2(raw[n2].x * tw.w[n2].x, raw[n2].y * tw.w[n2].y);
+        for (int n2 = 0; n2 < 8; ++n2) x[n2] = pk_mul(pk_v(raw[n2]), tw.w[n2]);
         wave_fft512<-1>(x, xb, tw, lane);
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = x[k2];                   // Z in natural order
@@ -191,16 +177,14 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 1 + lane + 64 * j;
-            const float2 za = xb[k], zb = cconj(xb[N2 - k]);
-            const float2 E = make_float2(0.5f * (za.x + zb.x), 0.5f * (za.y + zb.y));
-            const float2 dz = csub(za, zb);
-            const float2 O = make_float2(0.5f * dz.y, -0.5f * dz.x);
-            const float2 T = cmulf(tw.p[j], O);
-            Xk[j] = cadd(E, T);
-            Xm[j] = cconj(csub(E, T));
+            const v2f za = xb[k], zbr = xb[N2 - k];
+            const v2f E2 = pk_add_conj(za, zbr), dz = pk_sub_conj(za, zbr);
+            const v2f T = pk_cmul(tw.pm[j], dz);
+            Xk[j] = pk_fma(E2, half, T);
+            Xm[j] = pk_fma_cnjm(E2, half, T);
         }
         {
-            const float2 z0 = xb[0];
+            const v2f z0 = xb[0];
             X0 = make_float2(z0.x + z0.y, 0.f);
             XN = make_float2(z0.x - z0.y, 0.f);
         }
@@ -210,8 +194,8 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 1 + lane + 64 * j;
-            Xk[j] = S[k];
-            Xm[j] = S[N2 - k];
+            Xk[j] = pk_v(S[k]);
+            Xm[j] = pk_v(S[N2 - k]);
         }
         X0 = S[0];
         XN = S[N2];
@@ -221,8 +205,8 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 1 + lane + 64 * j;
-            S[k] = Xk[j];
-            if (k != N2 - k) S[N2 - k] = Xm[j];
+            S[k] = pk_f(Xk[j]);
+            if (k != N2 - k) S[N2 - k] = pk_f(Xm[j]);
         }
         if (lane == 0) { S[0] = X0; S[N2] = XN; }
         return 0.f;
@@ -231,8 +215,8 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = 1 + lane + 64 * j;
-        Xk[j] = bin_op<OP>(Xk[j], k, c, wsum);
-        if (k != N2 - k) Xm[j] = bin_op<OP>(Xm[j], N2 - k, c, wsum); else Xm[j] = Xk[j];
+        Xk[j] = pk_v(bin_op<OP>(pk_f(Xk[j]), k, c, wsum));
+        if (k != N2 - k) Xm[j] = pk_v(bin_op<OP>(pk_f(Xm[j]), N2 - k, c, wsum)); else Xm[j] = Xk[j];
     }
     {
         float w0 = 0.f;
@@ -241,27 +225,25 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
         if (lane == 0) wsum += w0;
         X0.y = 0.f; XN.y = 0.f;                               // irfft ignores Im(DC), Im(Nyquist)
     }
-    // ---- inverse pre-pass: Z'[k] = Ee + i Oo, Z'[512 - k] = conj(Ee - i Oo), Ee = X[k] + conj X[512-k], Oo = (X[k] - conj X[512-k]) conj(w_k)
+    // ---- inverse pre-pass: Z'[k] = Ee + i Oo, Z'[512 - k] = conj(Ee - i Oo), Ee = X[k] + conj X[512-k], i Oo = 2 (X[k] - conj X[512-k]) conj(pm_k)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = 1 + lane + 64 * j;
-        const float2 xa = Xk[j], xm = cconj(Xm[j]);
-        const float2 Ee = cadd(xa, xm);
-        const float2 Oo = cmulf(csub(xa, xm), cconj(tw.p[j]));
-        const float2 iO = make_float2(-Oo.y, Oo.x);
-        xb[k] = cadd(Ee, iO);
-        xb[N2 - k] = cconj(csub(Ee, iO));                      // k = 256: both stores carry the same value
+        const v2f Ee = pk_add_conj(Xk[j], Xm[j]), d = pk_sub_conj(Xk[j], Xm[j]);
+        const v2f W = pk_cmul_conj(d, tw.pm[j]);
+        xb[k] = pk_fma(W, two, Ee);
+        xb[N2 - k] = pk_fma_cnjn(W, two, Ee);                  // k = 256: both stores carry the same value
     }
-    if (lane == 0) xb[0] = make_float2(X0.x + XN.x, X0.x - XN.x);
+    if (lane == 0) xb[0] = v2f{X0.x + XN.x, X0.x - XN.x};
     wave_fence();
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) x[n2] = xb[lane + 64 * n2];
     wave_fence();
     wave_fft512<+1>(x, xb, tw, lane);
     // x[k2] = 1024 z[lane + 64 k2]: samples 2m, 2m + 1 of the frame; window again (istft), keep in LDS
-    const float inv = 1.f / (float)N;
+    const v2f inv = {1.f / (float)N, 1.f / (float)N};
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(x[k2].x * inv * tw.w[k2].x, x[k2].y * inv * tw.w[k2].y);
+    for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = pk_mul(pk_mul(x[k2], inv), tw.w[k2]);
     return wsum;
 }
 
@@ -426,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
             for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(0.f, 0.f);
         }
         if (it + 1 < niter && t + NW >= 0 && t + NW < t_end) frame_load(a, xr, t + NW, lane, raw);
-        __syncthreads();                                      // this iteration's frames are in LDS
+        lds_barrier();                                        // this iteration's frames are in LDS
         if (t >= J0 && t < J1) {                              // block j = t <- frames t-3 .. t = slots wave-3 .. wave at offsets 768, 512, 256, 0
             const int j = t;
             const float* fq[4];
@@ -465,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
                 }
             }
         }
-        __syncthreads();                                      // every block of the iteration is out: results may be overwritten
+        lds_barrier();                                        // every block of the iteration is read: results may be overwritten
         if (wave >= NW - 3 && it + 1 < niter) {               // the next iteration's blocks reach back three frames
             const float4* src = reinterpret_cast<const float4*>(xb);
             float4* dst = reinterpret_cast<float4*>(carry + (wave - (NW - 3)) * N);

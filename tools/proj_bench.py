@@ -84,6 +84,10 @@ def roofline_block(dev="cuda", L=160000, B=32):
 
 
 if __name__ == "__main__":
+    if "--batch-only" in sys.argv:          # counter passes (tools/fft_pmc.sh): the (32, L) launches only
+        res = measure(SPECTRAL, rows_list=(32,), iters=10)
+        print(json.dumps(res))
+        sys.exit(0)
     res = measure(SPECTRAL if "--spectral" in sys.argv else ALL)
     res += measure(SPECTRAL if "--spectral" in sys.argv else ALL, in_place=True)
     print(json.dumps(res))
