@@ -67,7 +67,7 @@ def roofline_block(dev="cuda", L=160000, B=32):
     reference shape (1, L).  Timed with HIP events on the launch stream, 50 calls each."""
     rows = measure(SPECTRAL, (1, B), L, B, 50, dev, verbose=False)
     inpl = measure(SPECTRAL, (1,), L, B, 50, dev, verbose=False, in_place=True)
-    blk = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernel": "k_spec_fused<OP> (STFT -> per-bin op -> iSTFT + overlap-add, one launch; + scale launch for fletcher_munson)",
+    blk = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernel": "k_spec_run<OP, 12> at (32, L), k_spec_fused<OP, ., 8> at (1, L) (STFT -> per-bin op -> iSTFT + overlap-add, one launch; + scale launch for fletcher_munson)",
            "algorithmic_bytes": 8 * B * L, "shape": [B, L], "call": "paa_project_to (out of place)", "norms": {}}
     for r in rows:
         d = blk["norms"].setdefault(r["norm"], {})
