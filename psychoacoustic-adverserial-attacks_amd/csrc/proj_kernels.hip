@@ -453,6 +453,15 @@ extern "C" paa_status paa_proj_create(paa_proj** out, int n_fft, int hop, int wi
     return PAA_OK;
 }
 
+#ifdef PAA_SPEC_STAMP
+// diagnostic builds only (tools/fft_stamps.py): the per-iteration s_memtime stamps k_spec_run left in the FM partial array
+extern "C" paa_status paa_debug_spec_stamps(paa_proj* h, long long* host, int n) {
+    PAA_HIP(hipDeviceSynchronize());
+    PAA_HIP(hipMemcpy(host, h->d_part + MAX_PART, sizeof(long long) * n, hipMemcpyDeviceToHost));
+    return PAA_OK;
+}
+#endif
+
 extern "C" void paa_proj_destroy(paa_proj* h) {
     if (!h) return;
     void* ptrs[] = {h->d_tw, h->d_win, h->d_fm, h->d_thr, h->d_thr_max, h->d_frames, h->d_part, h->d_scal};

@@ -34,7 +34,7 @@ constexpr int N = 1024, N2 = 512, HOP = 256, F = 513;
 struct LaneTw {
     v2f a[7];       // W512^(lane k0), k0 = 1..7
     v2f b[7];       // W64^((lane & 7) k1), k1 = 1..7
-    v2f pm[4];      // (-i / 2) e^{-2 pi i k / 1024}, k = 1 + lane + 64 j: the split post-pass's factor; the inverse pre-pass uses 2 conj(pm) = i conj(p)
+    v2f pm[4];      // (-i / 2) e^{-2 pi i k / 1024}, k = lane + 64 j: the split post-pass's factor; the inverse pre-pass uses 2 conj(pm) = i conj(p)
     v2f w[8];       // window at samples 2m, 2m + 1, m = lane + 64 n2
 };
 __device__ __forceinline__ void lane_tw(LaneTw& t, const float2* __restrict__ tw, const float* __restrict__ win, int lane) {
@@ -45,7 +45,7 @@ __device__ __forceinline__ void lane_tw(LaneTw& t, const float2* __restrict__ tw
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float2 p = tw[1 + lane + 64 * j];
+        const float2 p = tw[lane + 64 * j];
         t.pm[j] = v2f{0.5f * p.y, -0.5f * p.x};
     }
 #pragma unroll
@@ -162,83 +162,87 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
                                             const float2 (&raw)[8]) {
     v2f* xb = reinterpret_cast<v2f*>(xbf);
     v2f x[8];
-    v2f Xk[4], Xm[4];                                         // bins k = 1 + lane + 64 j and their mirrors 512 - k
-    float2 X0 = make_float2(0.f, 0.f), XN = make_float2(0.f, 0.f);      // DC, Nyquist
+    v2f Xk[4], Xm[4];                                         // bins k = lane + 64 j and their mirrors 512 - k (lane 0, j = 0: DC and Nyquist)
     float wsum = 0.f;
     const v2f half = {0.5f, 0.5f}, two = {2.f, 2.f};
+    // Bin ownership: a lane owns bins k_j = lane + 64 j (j < 4) — its OWN registers x[j] after the forward transform — and their mirrors
+    // 512 - k_j, which sit in lane 64 - lane, register 7 - j: one ds_bpermute pair per mirror (a pull through the LDS crossbar, no
+    // memory), instead of writing Z in natural order and reading the pairs back.  Lane 0 is special three times: its mirrors are its own
+    // registers 8 - j (j = 1..3), its pair j = 0 is (DC, Nyquist), and its register 4 is bin 256, its own mirror.
+    const bool l0 = lane == 0;
+    const int mirror = ((64 - lane) & 63) << 2;              // ds_bpermute address (bytes) of the partner lane
+    v2f X256 = {0.f, 0.f};
     if (!SRC_SPEC) {
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) x[n2] = pk_mul(pk_v(raw[n2]), tw.w[n2]);
         wave_fft512<-1>(x, xb, tw, lane);
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = x[k2];                   // Z in natural order
-        wave_fence();
         // split post-pass: X[k] = E + T, X[512 - k] = conj(E - T), E = (Z[k] + conj Z[512-k]) / 2, T = w_k (-i/2)(Z[k] - conj Z[512-k])
+        v2f m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = pk_bpermute(mirror, x[7 - j]);
+        m[1] = l0 ? x[7] : m[1]; m[2] = l0 ? x[6] : m[2]; m[3] = l0 ? x[5] : m[3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = 1 + lane + 64 * j;
-            const v2f za = xb[k], zbr = xb[N2 - k];
-            const v2f E2 = pk_add_conj(za, zbr), dz = pk_sub_conj(za, zbr);
+            const v2f E2 = pk_add_conj(x[j], m[j]), dz = pk_sub_conj(x[j], m[j]);
             const v2f T = pk_cmul(tw.pm[j], dz);
             Xk[j] = pk_fma(E2, half, T);
             Xm[j] = pk_fma_cnjm(E2, half, T);
         }
-        {
-            const v2f z0 = xb[0];
-            X0 = make_float2(z0.x + z0.y, 0.f);
-            XN = make_float2(z0.x - z0.y, 0.f);
-        }
-        wave_fence();
+        Xk[0] = l0 ? v2f{x[0].x + x[0].y, 0.f} : Xk[0];       // DC
+        Xm[0] = l0 ? v2f{x[0].x - x[0].y, 0.f} : Xm[0];       // Nyquist
+        X256 = v2f{x[4].x, -x[4].y};                          // lane 0: X[256] = conj Z[256]
     } else {
         const float2* S = reinterpret_cast<const float2*>(a.S_in) + ((size_t)row * a.T + t) * F;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = 1 + lane + 64 * j;
+            const int k = lane + 64 * j;
             Xk[j] = pk_v(S[k]);
             Xm[j] = pk_v(S[N2 - k]);
         }
-        X0 = S[0];
-        XN = S[N2];
+        X256 = pk_v(S[N2 / 2]);
     }
     if (DST_SPEC) {
         float2* S = reinterpret_cast<float2*>(a.S_out) + ((size_t)row * a.T + t) * F;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = 1 + lane + 64 * j;
+            const int k = lane + 64 * j;
             S[k] = pk_f(Xk[j]);
-            if (k != N2 - k) S[N2 - k] = pk_f(Xm[j]);
+            S[N2 - k] = pk_f(Xm[j]);
         }
-        if (lane == 0) { S[0] = X0; S[N2] = XN; }
+        if (l0) S[N2 / 2] = pk_f(X256);
         return 0.f;
     }
-    // ---- per-bin projection (bin 256 is its own mirror: projected once, counted once) ----
+    // ---- per-bin projection: 8 bins per lane + bin 256 (evaluated by every lane, kept and counted by lane 0) ----
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int k = 1 + lane + 64 * j;
+        const int k = lane + 64 * j;
         Xk[j] = pk_v(bin_op<OP>(pk_f(Xk[j]), k, c, wsum));
-        if (k != N2 - k) Xm[j] = pk_v(bin_op<OP>(pk_f(Xm[j]), N2 - k, c, wsum)); else Xm[j] = Xk[j];
+        Xm[j] = pk_v(bin_op<OP>(pk_f(Xm[j]), N2 - k, c, wsum));
     }
     {
-        float w0 = 0.f;
-        X0 = bin_op<OP>(X0, 0, c, w0);
-        XN = bin_op<OP>(XN, N2, c, w0);
-        if (lane == 0) wsum += w0;
-        X0.y = 0.f; XN.y = 0.f;                               // irfft ignores Im(DC), Im(Nyquist)
+        float w256 = 0.f;
+        X256 = pk_v(bin_op<OP>(pk_f(X256), N2 / 2, c, w256));
+        if (l0) wsum += w256;
     }
     // ---- inverse pre-pass: Z'[k] = Ee + i Oo, Z'[512 - k] = conj(Ee - i Oo), Ee = X[k] + conj X[512-k], i Oo = 2 (X[k] - conj X[512-k]) conj(pm_k)
+    {
+        v2f y[4], r[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = 1 + lane + 64 * j;
-        const v2f Ee = pk_add_conj(Xk[j], Xm[j]), d = pk_sub_conj(Xk[j], Xm[j]);
-        const v2f W = pk_cmul_conj(d, tw.pm[j]);
-        xb[k] = pk_fma(W, two, Ee);
-        xb[N2 - k] = pk_fma_cnjn(W, two, Ee);                  // k = 256: both stores carry the same value
+        for (int j = 0; j < 4; ++j) {
+            const v2f Ee = pk_add_conj(Xk[j], Xm[j]), d = pk_sub_conj(Xk[j], Xm[j]);
+            const v2f W = pk_cmul_conj(d, tw.pm[j]);
+            x[j] = pk_fma(W, two, Ee);                        // Z'[lane + 64 j]: already where the inverse transform wants it
+            y[j] = pk_fma_cnjn(W, two, Ee);                   // Z'[512 - k_j]: lane 64 - lane, register 7 - j
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = pk_bpermute(mirror, y[j]);
+        // lane 0: Z'[0] from (DC, Nyquist) — irfft ignores their imaginary parts —, Z'[64 (8 - j)] = its own y[j], Z'[256] = 2 conj X[256]
+        x[0] = l0 ? v2f{Xk[0].x + Xm[0].x, Xk[0].x - Xm[0].x} : x[0];
+        x[7] = l0 ? y[1] : r[0];
+        x[6] = l0 ? y[2] : r[1];
+        x[5] = l0 ? y[3] : r[2];
+        x[4] = l0 ? v2f{2.f * X256.x, -2.f * X256.y} : r[3];
     }
-    if (lane == 0) xb[0] = v2f{X0.x + XN.x, X0.x - XN.x};
-    wave_fence();
-#pragma unroll
-    for (int n2 = 0; n2 < 8; ++n2) x[n2] = xb[lane + 64 * n2];
-    wave_fence();
     wave_fft512<+1>(x, xb, tw, lane);
     // x[k2] = 1024 z[lane + 64 k2]: samples 2m, 2m + 1 of the frame; window again (istft), keep in LDS
     const v2f inv = {1.f / (float)N, 1.f / (float)N};
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
         if (OP == SOP_FM && tid == 0) a.part[(size_t)row * gridDim.x + g] = 0.0;
         return;
     }
-    float2* xb = xbuf + wave * XB;
+    float2* const xb = xbuf + wave * XB;
     float* carry = reinterpret_cast<float*>(xbuf + NW * XB);  // [3][1024]: frame slots NW-3 .. NW-1 of the previous iteration
     BinCtx c;
     c.fm = a.fm; c.thr = a.thr; c.thr_off = a.phon_ref - (OP == SOP_PHON ? a.thr_max[0] : 0.f);
@@ -398,8 +402,19 @@ __global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
     int t = J0 - 3 + wave;
     if (t >= 0 && t < t_end) frame_load(a, xr, t, lane, raw);
     float wsum = 0.f;
+#if defined(PAA_SPEC_STAMP) && !defined(PAA_EXPERIMENTS)
+#error "PAA_SPEC_STAMP is a diagnostic build: add -DPAA_EXPERIMENTS"
+#endif
+#ifdef PAA_SPEC_STAMP
+    // workgroup (0, 0): [wave][iteration][5] = loop top, frame done, past barrier A, overlap-add done, past barrier B
+    long long* stamp = reinterpret_cast<long long*>(a.part) + 64;
+#define SPEC_STAMP(slot) do { if (OP == SOP_MINMAX && g == 0 && row == 0 && lane == 0 && it < 8) stamp[(wave * 8 + it) * 5 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPEC_STAMP(slot) do { } while (0)
+#endif
 #pragma unroll 1
     for (int it = 0; it < niter; ++it, t += NW) {
+        SPEC_STAMP(0);
         if (t >= 0 && t < t_end) {
             const float ws = wave_frame<OP, false, false>(a, c, tw, xb, row, t, lane, raw);
             if (t >= J0 || g == 0) wsum += ws;                // halo frames belong to the previous run's sum
@@ -407,8 +422,10 @@ __global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) xb[lane + 64 * k2] = make_float2(0.f, 0.f);
         }
+        SPEC_STAMP(1);
         if (it + 1 < niter && t + NW >= 0 && t + NW < t_end) frame_load(a, xr, t + NW, lane, raw);
         lds_barrier();                                        // this iteration's frames are in LDS
+        SPEC_STAMP(2);
         if (t >= J0 && t < J1) {                              // block j = t <- frames t-3 .. t = slots wave-3 .. wave at offsets 768, 512, 256, 0
             const int j = t;
             const float* fq[4];
@@ -447,7 +464,9 @@ __global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
                 }
             }
         }
+        SPEC_STAMP(3);
         lds_barrier();                                        // every block of the iteration is read: results may be overwritten
+        SPEC_STAMP(4);
         if (wave >= NW - 3 && it + 1 < niter) {               // the next iteration's blocks reach back three frames
             const float4* src = reinterpret_cast<const float4*>(xb);
             float4* dst = reinterpret_cast<float4*>(carry + (wave - (NW - 3)) * N);

@@ -119,6 +119,13 @@ __device__ __forceinline__ void pk_swap(v2f& a, v2f& b) {
     a = v2f{__uint_as_float(ax), __uint_as_float(ay)};
     b = v2f{__uint_as_float(bx), __uint_as_float(by)};
 }
+// the value lane (addr / 4) holds: a pull through the LDS crossbar (ds_bpermute_b32), no LDS memory involved
+__device__ __forceinline__ v2f pk_bpermute(int addr, v2f v) {
+    const float fx = v.x, fy = v.y;
+    const int rx = __builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(fx));
+    const int ry = __builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(fy));
+    return v2f{__uint_as_float((unsigned)rx), __uint_as_float((unsigned)ry)};
+}
 __device__ __forceinline__ void pk_transpose_hi(v2f (&x)[8]) {
     pk_swap<5>(x[0], x[4]); pk_swap<5>(x[1], x[5]); pk_swap<5>(x[2], x[6]); pk_swap<5>(x[3], x[7]);
     pk_swap<4>(x[0], x[2]); pk_swap<4>(x[1], x[3]); pk_swap<4>(x[4], x[6]); pk_swap<4>(x[5], x[7]);
