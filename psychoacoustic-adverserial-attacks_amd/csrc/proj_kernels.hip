@@ -307,8 +307,9 @@ struct ApplyArgs {
     double clip_len;          //   numel_clean = ext_clips[0] * clip_len then replaces the host value above
 };
 
+// p = src * scale (src == p: in place; otherwise the out-of-place form reads the caller's source directly — no copy in front)
 template <int NORM>
-__global__ __launch_bounds__(RED_NT) void k_apply_scale(float* __restrict__ p, int64_t n, ApplyArgs a) {
+__global__ __launch_bounds__(RED_NT) void k_apply_scale(const float* src, float* p, int64_t n, ApplyArgs a) {
     __shared__ double red[RED_NT / 64];
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < a.g1; i += RED_NT) s1 += a.part[i];
@@ -336,13 +337,24 @@ __global__ __launch_bounds__(RED_NT) void k_apply_scale(float* __restrict__ p, i
         if (tv > eps) scale = eps / tv;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.scal) { a.scal[0] = scale; a.scal[1] = (float)s1; a.scal[2] = (float)s2; }
-    for (int64_t i = (int64_t)blockIdx.x * RED_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * RED_NT)
-        p[i] = p[i] * scale;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(p)) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* p4 = reinterpret_cast<float4*>(p);
+        for (int64_t i = (int64_t)blockIdx.x * RED_NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * RED_NT) {
+            float4 v = s4[i];
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            p4[i] = v;
+        }
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * RED_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * RED_NT) p[i] = src[i] * scale;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * RED_NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * RED_NT) p[i] = src[i] * scale;
+    }
 }
 
-__global__ void k_clamp(float* __restrict__ p, int64_t n, float lo, float hi) {
+__global__ void k_clamp(const float* src, float* p, int64_t n, float lo, float hi) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = fminf(fmaxf(p[i], lo), hi);       // torch.clamp propagates NaN; fminf/fmaxf do not: see DESIGN.md
+        p[i] = fminf(fmaxf(src[i], lo), hi);       // torch.clamp propagates NaN; fminf/fmaxf do not: see DESIGN.md
 }
 
 __global__ void k_sign_step(float* __restrict__ p, const float* __restrict__ g, float lr, int n) {
@@ -569,9 +581,11 @@ static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, i
         }
         return PAA_OK;
     }
-    if (d_src) {          // generic kernels work in place: copy first
+    const bool scale_type = nt == PAA_NORM_L2 || nt == PAA_NORM_SNR || nt == PAA_NORM_TV || nt == PAA_NORM_LINF;
+    if (d_src && !scale_type) {          // the generic frame kernels work in place: copy first
         PAA_HIP(hipMemcpyAsync(d_p, d_src, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
     }
+    const float* d_in = d_src ? d_src : d_p;      // scale-type norms and linf: the reduction and the scaling pass read the source directly
     switch (nt) {
         case PAA_NORM_FLETCHER_MUNSON:
         case PAA_NORM_MIN_MAX_FREQS:
@@ -597,7 +611,7 @@ static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, i
             return PAA_OK;
         }
         case PAA_NORM_LINF: {
-            hipLaunchKernelGGL(k_clamp, dim3(std::min(cdiv(n, 256), 2048)), dim3(256), 0, st, d_p, n, -prm->linf_size,
+            hipLaunchKernelGGL(k_clamp, dim3(std::min(cdiv(n, 256), 2048)), dim3(256), 0, st, d_in, d_p, n, -prm->linf_size,
                                prm->linf_size);
             PAA_LAUNCH_CHECK();
             return PAA_OK;
@@ -613,10 +627,10 @@ static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, i
             const int g1 = nc ? std::min(cdiv(nc, (int64_t)RED_NT * 16), 2048) : 0;
             const int g2 = std::min(cdiv(n, (int64_t)RED_NT * 8), 1024);
             if (nt == PAA_NORM_TV)
-                hipLaunchKernelGGL(k_reduce2<RED_TV>, dim3(g1 + g2), dim3(RED_NT), 0, st, d_clean, nc, L, g1, (const float*)d_p,
+                hipLaunchKernelGGL(k_reduce2<RED_TV>, dim3(g1 + g2), dim3(RED_NT), 0, st, d_clean, nc, L, g1, d_in,
                                    n, L, g2, h->d_part);
             else
-                hipLaunchKernelGGL(k_reduce2<RED_SQ>, dim3(g1 + g2), dim3(RED_NT), 0, st, d_clean, nc, L, g1, (const float*)d_p,
+                hipLaunchKernelGGL(k_reduce2<RED_SQ>, dim3(g1 + g2), dim3(RED_NT), 0, st, d_clean, nc, L, g1, d_in,
                                    n, L, g2, h->d_part);
             PAA_LAUNCH_CHECK();
             ApplyArgs a{};
@@ -626,9 +640,9 @@ static paa_status project_impl(paa_proj* h, const paa_params* prm, float* d_p, i
             a.snr_db = prm->snr_db; a.snr_linear = (float)pow(10.0, (double)prm->snr_db / 10.0);
             a.eps = (nt == PAA_NORM_L2) ? prm->l2_size : prm->tv_epsilon;
             const int ga = std::min(cdiv(n, 256), 1024);
-            if (nt == PAA_NORM_L2) hipLaunchKernelGGL(k_apply_scale<PAA_NORM_L2>, dim3(ga), dim3(RED_NT), 0, st, d_p, n, a);
-            else if (nt == PAA_NORM_SNR) hipLaunchKernelGGL(k_apply_scale<PAA_NORM_SNR>, dim3(ga), dim3(RED_NT), 0, st, d_p, n, a);
-            else hipLaunchKernelGGL(k_apply_scale<PAA_NORM_TV>, dim3(ga), dim3(RED_NT), 0, st, d_p, n, a);
+            if (nt == PAA_NORM_L2) hipLaunchKernelGGL(k_apply_scale<PAA_NORM_L2>, dim3(ga), dim3(RED_NT), 0, st, d_in, d_p, n, a);
+            else if (nt == PAA_NORM_SNR) hipLaunchKernelGGL(k_apply_scale<PAA_NORM_SNR>, dim3(ga), dim3(RED_NT), 0, st, d_in, d_p, n, a);
+            else hipLaunchKernelGGL(k_apply_scale<PAA_NORM_TV>, dim3(ga), dim3(RED_NT), 0, st, d_in, d_p, n, a);
             PAA_LAUNCH_CHECK();
             return PAA_OK;
         }
@@ -746,7 +760,7 @@ extern "C" paa_status paa_clamp(float* d_p, int64_t n, float lo, float hi, void*
     if (!d_p) PAA_FAIL(PAA_ERR_ARG, "paa_clamp: null argument");
     if (n < 1) PAA_FAIL(PAA_ERR_SIZE, "paa_clamp: n=%lld", (long long)n);
     // lo > hi: every element becomes hi, as torch.clamp documents (min(max(x, lo), hi))
-    hipLaunchKernelGGL(k_clamp, dim3(std::min(cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, d_p, n, lo, hi);
+    hipLaunchKernelGGL(k_clamp, dim3(std::min(cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, (const float*)d_p, d_p, n, lo, hi);
     PAA_LAUNCH_CHECK();
     return PAA_OK;
 }

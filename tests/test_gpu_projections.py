@@ -232,3 +232,27 @@ def test_run_kernel_rows_vs_single_row_kernel_and_oracle(rows, L):
             sel = x[picked]
             ref = OP.perturbation_constraint(sel, sel, args, OP.spl_thresh_tensor(args)).numpy()
             assert rel_err(many[picked].cpu().numpy(), ref) <= TOL, norm
+
+
+def test_out_of_place_equals_in_place_scale_norms():
+    """l2 / snr / tv / linf: paa_project_to reduces over and scales the SOURCE directly (no copy in front); it must equal
+    paa_project on a clone bit for bit, at (1, L), (32, L) and a length that is not a multiple of four (scalar tail of the
+    16-byte scaling loop)."""
+    from paa_amd import _lib, runtime
+    lib = _lib.lib()
+    for L in (160000, 40001):
+        x = torch.from_numpy(synth.clean_audio(32, L)).cuda() * 0.3
+        clean = torch.from_numpy(synth.clean_audio(4, L)).cuda()
+        for norm, extra in (("l2", []), ("snr", ["--snr_db", "40"]), ("tv", []), ("linf", ["--linf_size", "1e-3"])):
+            args = _args(norm, extra)
+            pr = runtime.get_proj(args, x.device, 32, L)
+            prm = runtime.params_of(args)
+            for rows in (1, 32):
+                src = x[:rows].contiguous()
+                a = src.clone()
+                _lib.check(lib.paa_project(pr.h, prm, _lib.ptr(a), rows, _lib.ptr(clean), 4, L, _lib.stream_ptr()))
+                b = torch.full_like(src, float("nan"))
+                _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(src), _lib.ptr(b), rows, _lib.ptr(clean), 4, L, _lib.stream_ptr()))
+                assert torch.equal(a, b), (norm, rows, L)
+                assert torch.equal(src, x[:rows]), "the source must stay untouched"
+                assert float((a - src).abs().max()) > 0, (norm, rows, "projection did nothing: pick a smaller bound")
