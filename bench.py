@@ -67,9 +67,66 @@ def parse():
                     help="launch every step eagerly; default: the step is replayed from captured hipGraphs (BASELINE.md section 3 protocol; "
                          "same kernels, bit-identical results, same time — profiles/r3_graph_vs_eager_ab.txt), except the last "
                          "--prof_steps timed steps, which are launched eagerly so that HIP events can bracket every GEMM")
-    ap.add_argument("--pmc_json", default=None, help="tools/pmc_summary.py output of THIS commit: fills roofline.traffic (else null)")
+    ap.add_argument("--pmc_json", default=None, help="tools/pmc_summary.py output of THIS commit: fills roofline.traffic instead of the live counter passes")
+    ap.add_argument("--no_pmc", action="store_true",
+                    help="skip the live HBM-traffic measurement (two short rocprofv3 --pmc child runs of the headline mode BEFORE this process "
+                         "touches the GPU; N = 1 only); roofline.traffic is then null unless --pmc_json is given")
     ap.add_argument("--no_fft_bench", action="store_true", help="skip the FFT / projection path timing (roofline_fft block)")
     return ap.parse_args()
+
+
+def live_pmc(ar, mode):
+    """HBM bytes per launch of every GEMM variant of the headline mode, measured NOW: two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no other trace domain; KB units x 1024,
+    FETCH_SIZE doubled: MI355X_MICROARCH.md, HBM / rocprofv3 — the arithmetic of tools/pmc_summary.py), same shape flags, 1 warm-up +
+    2 timed eager steps.  Started before this process makes any GPU call.  -> ({variant: bytes per launch}, note) or (None, why)."""
+    import glob
+    import importlib.util
+    import shutil
+    import tempfile
+    if any(k.startswith(("ROCPROFILER_", "ROCP_TOOL", "ROCPROF_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(here, "tools", "pmc_summary.py"))
+        ps = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ps)
+    except Exception as e:                               # noqa: BLE001
+        return None, f"tools/pmc_summary.py: {e}"
+    tmp = tempfile.mkdtemp(prefix="paa_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--dtype", mode, "--steps", "2", "--warmup", "1", "--eager", "--no_cpu_baseline",
+             "--no_fft_bench", "--no_prof", "--no_pmc", "--batch", str(ar.batch), "--seconds", str(ar.seconds), "--arch", ar.arch,
+             "--norm_type", ar.norm_type, "--snr_db", str(ar.snr_db), "--label_tokens", str(ar.label_tokens)]
+    tot, cnt = {}, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "runc", "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            if r.returncode != 0 or not glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
+            t, c = ps.load(d, counter)
+            if not any(ps.variant_of(nm) for nm in t):
+                return None, (f"the --pmc {counter} pass recorded no GEMM launch (kernels seen: {sorted(t)[:6]}; child stderr tail: "
+                              f"{r.stderr[-400:]!r})")
+            scale = 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+            for name, v in t.items():
+                lab = ps.variant_of(name)
+                if lab:
+                    tot[lab] = tot.get(lab, 0.0) + v * scale
+                    if counter == "FETCH_SIZE":
+                        cnt[lab] = cnt.get(lab, 0) + c[name]
+    except Exception as e:                               # noqa: BLE001
+        return None, f"live counter passes: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {lab: int(tot[lab] / cnt[lab]) for lab in tot if cnt.get(lab)}
+    return out, ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of the same command "
+                 "(--steps 2 --warmup 1 --eager), KB x 1024, FETCH_SIZE x 2 (gfx950)")
 
 
 def spawn_ranks(n: int) -> int:
@@ -154,6 +211,11 @@ def main():
             raise SystemExit(f"unknown mode {m!r}")
     if "WORLD_SIZE" not in os.environ and ar.gpus > 1:
         sys.exit(spawn_ranks(ar.gpus))
+    live_traffic, live_note = None, "not measured (N > 1, --no_pmc or --no_prof)"
+    if ar.gpus == 1 and "WORLD_SIZE" not in os.environ and not ar.no_pmc and not ar.no_prof and not ar.pmc_json:
+        live_traffic, live_note = live_pmc(ar, modes[0])          # child processes; this one has not touched the GPU yet
+        if live_traffic is None:
+            sys.stderr.write(f"[bench] roofline.traffic stays null: {live_note}\n")
 
     import numpy as np
     import torch
@@ -316,8 +378,16 @@ def main():
                                 traffic = k["hbm_bytes_per_launch"]
                     except Exception:
                         traffic = None
+                traffic_source = "--pmc_json" if traffic is not None else None
+                if traffic is None and live_traffic is not None and dtype == modes[0]:
+                    if VARIANTS[v] in live_traffic:
+                        traffic, traffic_source = live_traffic[VARIANTS[v]], live_note
+                    else:
+                        sys.stderr.write(f"[bench] roofline.traffic stays null: the counter passes saw no launch labelled {VARIANTS[v]} "
+                                         f"(labels: {sorted(live_traffic)})\n")
                 roofline = {"bound": "mfma", "kernel": VARIANTS[v], "achieved": round(achieved, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                            "frac": round(achieved / MFMA_PEAK, 4), "traffic": traffic, "launches": int(n),
+                            "frac": round(achieved / MFMA_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
+                            "traffic_over_algorithmic": (round(traffic / (by / n), 3) if traffic else None), "launches": int(n),
                             "avg_launch_us": round(ms * 1e3 / n, 2), "algorithmic_bytes_per_launch": int(by / n),
                             "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1),
                             "mfma_passes_per_product": passes, "mfma_issue_frac": round(passes * achieved / MFMA_PEAK, 4),

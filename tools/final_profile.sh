@@ -17,12 +17,12 @@ timeout -k 10 400 python bench.py --steps 64 --warmup 5 > $O/bench.json 2> $O/be
 cut -c1-200 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 for DT in fp32 bf16; do
-  timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$DT -o runc -- python3 $R/bench.py --dtype $DT --steps 3 --warmup 1 --eager --no_cpu_baseline --no_fft_bench > $O/bench_under_rocprof_$DT.log 2>&1 || { echo "rocprof $DT failed"; tail -5 $O/bench_under_rocprof_$DT.log; }
+  timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$DT -o runc -- python3 $R/bench.py --dtype $DT --steps 3 --warmup 1 --eager --no_cpu_baseline --no_fft_bench --no_pmc > $O/bench_under_rocprof_$DT.log 2>&1 || { echo "rocprof $DT failed"; tail -5 $O/bench_under_rocprof_$DT.log; }
   find $O/prof_$DT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${DT}_kernel_stats.csv
   find $O/prof_$DT -name "*kernel_trace.csv" -delete
   grep "^{" $O/bench_under_rocprof_$DT.log | cut -c1-160
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 250 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${DT}_$C -o runc -- python3 $R/bench.py --dtype $DT --steps 2 --warmup 1 --eager --no_cpu_baseline --no_fft_bench --no_prof > $O/pmc_${DT}_$C.log 2>&1 || echo "pmc $DT $C failed"
+    timeout -k 10 250 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${DT}_$C -o runc -- python3 $R/bench.py --dtype $DT --steps 2 --warmup 1 --eager --no_cpu_baseline --no_fft_bench --no_prof --no_pmc > $O/pmc_${DT}_$C.log 2>&1 || echo "pmc $DT $C failed"
   done
   (cd $R && python tools/pmc_summary.py $O/pmc_${DT}_FETCH_SIZE $O/pmc_${DT}_WRITE_SIZE 4 $DT $O/bench.json > $O/hbm_traffic_pmc_$DT.json) || echo "pmc summary $DT failed"
   rm -rf $O/pmc_${DT}_FETCH_SIZE $O/pmc_${DT}_WRITE_SIZE

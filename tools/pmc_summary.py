@@ -35,7 +35,7 @@ def variant_of(kernel: str):
     m = re.search(r"k_gemm_ring2?<(\d+), (\d+), (\d+), (\d+)", kernel)
     if m:
         return f"k_gemm_ring<{m.group(1)},{m.group(2)},{'split' if m.group(4) == '1' else 'bf16'}>"
-    m = re.search(r"k_gemm_bf<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>", kernel)
+    m = re.search(r"k_gemm_bf<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)(?:, \w+)*>", kernel)
     if m:
         bm, bn, prec = m.group(1), m.group(2), "split" if m.group(3) == "1" else "bf16"
         if bm in ("256", "192") and m.group(5) == "true" and m.group(6) == "false":
