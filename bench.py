@@ -105,14 +105,22 @@ def live_pmc(ar, mode):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "runc", "--"] + child,
-                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-            if r.returncode != 0 or not glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-300:]}"
+            # own session: a pass that overruns is killed as a whole (profiler AND the profiled child), so nothing of it is left on
+            # the GPU when the timed region of this process starts
+            pr = subprocess.Popen([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "runc", "--"] + child,
+                                  cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=180)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.communicate()
+                return None, f"rocprofv3 --pmc {counter} pass exceeded 180 s and was killed"
+            if pr.returncode != 0 or not glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {pr.returncode}): {err[-300:]}"
             t, c = ps.load(d, counter)
             if not any(ps.variant_of(nm) for nm in t):
-                return None, (f"the --pmc {counter} pass recorded no GEMM launch (kernels seen: {sorted(t)[:6]}; child stderr tail: "
-                              f"{r.stderr[-400:]!r})")
+                return None, f"the --pmc {counter} pass recorded no GEMM launch (child stderr tail: {err[-300:]!r})"
             scale = 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
             for name, v in t.items():
                 lab = ps.variant_of(name)
