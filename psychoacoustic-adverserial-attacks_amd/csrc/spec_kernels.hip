@@ -90,11 +90,15 @@ __device__ __forceinline__ void wave_fft512(v2f (&x)[8], v2f* xb, const LaneTw& 
 struct BinCtx {
     const float* fm; const float* thr; float thr_off;      // thr_off = phon_ref - max(thr)
     float bin_hz, min_f, max_f;
+    int fs = F;             // row stride of the FM table (the run kernel's LDS copy pads its rows to FM_LS)
+    unsigned inb = 0;       // run kernel, FM: bit `slot` set = the lane's bin of that slot lies inside the interpolator (fm[k] >= 0), read once per run
+    bool have_inb = false;
 };
+constexpr int FM_LS = 576;  // 9 x 64: the two table rows of a lerp are then ONE ds_read2st64_b32
 
 // projections.py:68-159 on one bin.  FM leaves the bin untouched and returns |S|^2 w in `wsum`.
 template <int OP>
-__device__ __forceinline__ float2 bin_op(float2 v, int k, const BinCtx& c, float& wsum) {
+__device__ __forceinline__ float2 bin_op(float2 v, int k, const BinCtx& c, float& wsum, int slot = 0) {
     if (OP == SOP_MINMAX) {                      // projections.py:68-80: keep bins OUTSIDE [min, max]
         const float f = (float)k * c.bin_hz;
         const float m = ((f < c.min_f) || (f > c.max_f)) ? 1.f : 0.f;
@@ -118,13 +122,14 @@ __device__ __forceinline__ float2 bin_op(float2 v, int k, const BinCtx& c, float
         const float pw = v.x * v.x + v.y * v.y;  // abs() ** 2 without the round trip through the square root
         const float s = 3.01029995663981195f * __builtin_amdgcn_logf(pw + 1e-10f);                   // 10 log10(x) via log2
         float w = 1.f;
-        const float w0 = c.fm[k];
-        if (w0 >= 0.f && s >= 0.f && s <= 90.f) {
+        const bool inside = c.have_inb ? ((c.inb >> slot) & 1u) != 0 : c.fm[k] >= 0.f;
+        if (inside && s >= 0.f && s <= 90.f) {
             int i = (int)floorf(s * 0.1f);
             i = i > 8 ? 8 : i;
             if (s <= 10.f * (float)i && i > 0) i -= 1;       // searchsorted(side='left') - 1
             const float ys = (s - 10.f * (float)i) * 0.1f;
-            w = c.fm[i * F + k] * (1.f - ys) + c.fm[(i + 1) * F + k] * ys;
+            const float* tb = c.fm + i * c.fs + k;
+            w = tb[0] * (1.f - ys) + tb[c.fs] * ys;
         }
         wsum += pw * w;
         return v;
@@ -216,12 +221,12 @@ __device__ __forceinline__ float wave_frame(const SpecArgs& a, const BinCtx& c, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = lane + 64 * j;
-        Xk[j] = pk_v(bin_op<OP>(pk_f(Xk[j]), k, c, wsum));
-        Xm[j] = pk_v(bin_op<OP>(pk_f(Xm[j]), N2 - k, c, wsum));
+        Xk[j] = pk_v(bin_op<OP>(pk_f(Xk[j]), k, c, wsum, j));
+        Xm[j] = pk_v(bin_op<OP>(pk_f(Xm[j]), N2 - k, c, wsum, 4 + j));
     }
     {
         float w256 = 0.f;
-        X256 = pk_v(bin_op<OP>(pk_f(X256), N2 / 2, c, w256));
+        X256 = pk_v(bin_op<OP>(pk_f(X256), N2 / 2, c, w256, 8));
         if (l0) wsum += w256;
     }
     // ---- inverse pre-pass: Z'[k] = Ee + i Oo, Z'[512 - k] = conj(Ee - i Oo), Ee = X[k] + conj X[512-k], i Oo = 2 (X[k] - conj X[512-k]) conj(pm_k)
@@ -387,8 +392,16 @@ __global__ __launch_bounds__(NW * 64) void k_spec_run(SpecArgs a, int bpr) {
     c.bin_hz = a.bin_hz; c.min_f = a.min_f; c.max_f = a.max_f;
     if (OP == SOP_FM) {
         float* fml = reinterpret_cast<float*>(xbuf + TAIL) + 64;
-        for (int i = tid; i < 10 * F; i += NW * 64) fml[i] = a.fm[i];
-        c.fm = fml;
+        for (int i = tid; i < 10 * F; i += NW * 64) fml[(i / F) * FM_LS + i % F] = a.fm[i];
+        // which of the lane's nine bins lie inside the interpolator does not change from frame to frame
+        unsigned inb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            inb |= (a.fm[lane + 64 * j] >= 0.f ? 1u : 0u) << j;
+            inb |= (a.fm[N2 - (lane + 64 * j)] >= 0.f ? 1u : 0u) << (4 + j);
+        }
+        inb |= (a.fm[N2 / 2] >= 0.f ? 1u : 0u) << 8;
+        c.fm = fml; c.fs = FM_LS; c.inb = inb; c.have_inb = true;
         __syncthreads();
     }
     const int niter = (J1 - J0 + 3 + NW - 1) / NW;
@@ -578,7 +591,7 @@ paa_status launch_fused_nw(const SpecArgs& a, int rows, hipStream_t st) {
 template <int OP>
 paa_status launch_run(const SpecArgs& a, int rows, int runs, hipStream_t st) {
     constexpr int NW = RUN_NW;
-    const size_t lds = sizeof(float2) * (NW * XB + 3 * N2) + 256 + (OP == SOP_FM ? sizeof(float) * 10 * F : 0);
+    const size_t lds = sizeof(float2) * (NW * XB + 3 * N2) + 256 + (OP == SOP_FM ? sizeof(float) * 10 * FM_LS : 0);
     static bool attr = false;                                 // > 64 KB of dynamic LDS needs the attribute (per code object: set once)
     if (!attr) { PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spec_run<OP, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     hipLaunchKernelGGL((k_spec_run<OP, NW>), dim3(runs, rows), dim3(NW * 64), lds, st, a, cdiv(a.T - 1, runs));
