@@ -185,14 +185,15 @@ def test_out_of_place_equals_in_place_and_batched_rows():
             _lib.check(lib.paa_project_to(pr.h, prm, _lib.ptr(x), _lib.ptr(x), 32, None, 0, L, _lib.stream_ptr()))
 
 
-@pytest.mark.parametrize("rows,L", [(32, 160000), (24, 40001), (9, 480000), (40, 33000)])
+@pytest.mark.parametrize("rows,L", [(32, 160000), (24, 40001), (9, 480000), (40, 33000), (300, 2048), (64, 5000), (33, 1100), (600, 700)])
 def test_run_kernel_rows_vs_single_row_kernel_and_oracle(rows, L):
     """Batched shapes go through the run-walking kernel (k_spec_run: carried frames, prefetched samples, per-wave
     overlap-add); a single row goes through the slab kernel (k_spec_fused, 8 frames).  Same per-frame arithmetic and the
     same overlap-add order — the two differ only where the compiler contracts a product and a sum into an fma (measured
     1.7e-7 of the peak), so every checked row of the batch must equal that row projected alone to 1e-6 of the peak, and the
     oracle to TOL: odd L (reflect path on every frame, scalar stores), L not a multiple of the hop (zero tail), 30 s rows
-    (11 iterations per run), more rows than a round of workgroups."""
+    (11 iterations per run), more rows than a round of workgroups, rows of a few frames only (one short run per row, every frame
+    touching the reflect padding)."""
     from paa_amd import _lib, runtime
     lib = _lib.lib()
     g = torch.Generator().manual_seed(rows * 1000003 + L)
