@@ -1,8 +1,9 @@
-// Unit check of csrc/spec_pk.h on the device against host arithmetic: hipcc --offload-arch=gfx950 -O3 -o pk_test pk_test.hip
+// Unit check of csrc/spec_pk.h on the device against host arithmetic (built and run by tests/test_gpu_kernels.py::test_spec_pk_primitives):
+//   hipcc --offload-arch=gfx950 -O3 -o spec_pk_test tests/hip/spec_pk_test.hip && ./spec_pk_test
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <math.h>
-#include "../../psychoacoustic-adverserial-attacks_amd/csrc/spec_pk.h"
+#include "../../psychoacoustic-adverserial-attacks_amd/csrc/spec_pk.h"   // tests/hip -> repo root
 using namespace paa;
 constexpr int NP = 16;
 __global__ void k(const float2* in, float2* out) {
@@ -28,10 +29,13 @@ __global__ void kt(unsigned* out) {
     for (int r = 0; r < 8; ++r) x[r] = v2f{(float)(r * 64 + l), (float)(1000 + r * 64 + l)};
     pk_transpose_hi(x);
     for (int r = 0; r < 8; ++r) { out[(r * 64 + l) * 2] = (unsigned)x[r].x; out[(r * 64 + l) * 2 + 1] = (unsigned)x[r].y; }
+    // mirror pull of the split post / pre passes: lane l reads lane (64 - l) & 63
+    const v2f m = pk_bpermute(((64 - l) & 63) << 2, v2f{(float)l, (float)(100 + l)});
+    out[1024 + 2 * l] = (unsigned)m.x; out[1024 + 2 * l + 1] = (unsigned)m.y;
 }
 int main() {
     {
-        unsigned* o; static unsigned h[1024];
+        unsigned* o; static unsigned h[1024 + 128];
         hipMalloc(&o, sizeof(h));
         hipLaunchKernelGGL(kt, dim3(1), dim3(64), 0, 0, o);
         hipMemcpy(h, o, sizeof(h), hipMemcpyDeviceToHost);
@@ -43,6 +47,10 @@ int main() {
                 if (h[(r * 64 + l) * 2] != want || h[(r * 64 + l) * 2 + 1] != 1000 + want) { if (bad < 8) printf("transpose r=%d l=%d got %u %u want %u\n", r, l, h[(r * 64 + l) * 2], h[(r * 64 + l) * 2 + 1], want); ++bad; }
             }
         printf("transpose_hi: %d wrong\n", bad);
+        for (int l = 0; l < 64; ++l) {
+            const unsigned want = (64 - l) & 63;
+            if (h[1024 + 2 * l] != want || h[1024 + 2 * l + 1] != 100 + want) { printf("bpermute l=%d got %u %u want %u\n", l, h[1024 + 2 * l], h[1024 + 2 * l + 1], want); ++bad; }
+        }
         if (bad) { printf("FAIL\n"); return 1; }
     }
     float2 h[192], *d, *o;

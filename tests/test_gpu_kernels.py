@@ -591,3 +591,21 @@ def test_fused_attention_split(T, B, nh):
     print(f"split attention T={T}: O {e_o:.2e} dQ {e_q:.2e} dK {e_k:.2e} dV {e_v:.2e}")
     assert e_o < 5e-5 and e_q < 1e-4 and e_k < 1e-4 and e_v < 1e-4
     assert float(ch[:, T:].abs().max()) == 0 and float(gh[:, T:].abs().max()) == 0
+
+
+def test_spec_pk_primitives(tmp_path):
+    """csrc/spec_pk.h: the packed-f32 instructions of the wave FFT are written out with operand modifiers (op_sel / op_sel_hi /
+    neg_lo / neg_hi), the first radix-8 exchange as permlane swaps + DPP moves.  tests/hip/spec_pk_test.hip runs every primitive, both
+    radix-8 butterflies and the 8 x 8 register/lane transpose on the device against host arithmetic: the modifier semantics are
+    checked directly, not only through the projections' goldens."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this box")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip", "spec_pk_test.hip")
+    exe = str(tmp_path / "spec_pk_test")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-Wno-unused-result", "-o", exe, src], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "transpose_hi: 0 wrong" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
