@@ -97,7 +97,9 @@ def live_pmc(ar, mode):
     except Exception as e:                               # noqa: BLE001
         return None, f"tools/pmc_summary.py: {e}"
     tmp = tempfile.mkdtemp(prefix="paa_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                            "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env["TMPDIR"] = "/tmp"
     child = [sys.executable, os.path.abspath(__file__), "--dtype", mode, "--steps", "2", "--warmup", "1", "--eager", "--no_cpu_baseline",
              "--no_fft_bench", "--no_prof", "--no_pmc", "--batch", str(ar.batch), "--seconds", str(ar.seconds), "--arch", ar.arch,
              "--norm_type", ar.norm_type, "--snr_db", str(ar.snr_db), "--label_tokens", str(ar.label_tokens)]
@@ -220,7 +222,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and ar.gpus > 1:
         sys.exit(spawn_ranks(ar.gpus))
     live_traffic, live_note = None, "not measured (N > 1, --no_pmc or --no_prof)"
-    if ar.gpus == 1 and "WORLD_SIZE" not in os.environ and not ar.no_pmc and not ar.no_prof and not ar.pmc_json:
+    if ar.gpus == 1 and os.environ.get("WORLD_SIZE", "1") == "1" and not ar.no_pmc and not ar.no_prof and not ar.pmc_json:
         live_traffic, live_note = live_pmc(ar, modes[0])          # child processes; this one has not touched the GPU yet
         if live_traffic is None:
             sys.stderr.write(f"[bench] roofline.traffic stays null: {live_note}\n")
