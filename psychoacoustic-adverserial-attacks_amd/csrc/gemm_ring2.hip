@@ -37,6 +37,16 @@ namespace {
 #ifndef PAA_R2_DEFER
 #define PAA_R2_DEFER 1
 #endif
+// cache-policy bits of the A / B operand DMA (diagnostic builds: 1 = sc0, 2 = nt, 16 = sc1); 0 = plain loads
+#if (defined(PAA_R2_A_AUX) || defined(PAA_R2_B_AUX)) && !defined(PAA_EXPERIMENTS)
+#error "PAA_R2_A_AUX / PAA_R2_B_AUX are diagnostic builds: add -DPAA_EXPERIMENTS"
+#endif
+#ifndef PAA_R2_A_AUX
+#define PAA_R2_A_AUX 0
+#endif
+#ifndef PAA_R2_B_AUX
+#define PAA_R2_B_AUX 0
+#endif
 typedef __attribute__((address_space(1))) const void* gas_ptr2;
 typedef __attribute__((address_space(3))) void* las_ptr2;
 template <int N>
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         unsigned char* st = smA + ca.slot * ASZ;
 #pragma unroll
         for (int i = 0; i < GA; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcA[i] + (int64_t)ca.slab * (AIL ? 2 * BK : BK)), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcA[i] + (int64_t)ca.slab * (AIL ? 2 * BK : BK)), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, PAA_R2_A_AUX);
         if (advance(ca, NSTA) && ca.t < total) set_srcA(ca.t);
         return true;
     };
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
         unsigned char* st = smB + cb.slot * BSZ;
 #pragma unroll
         for (int i = 0; i < GB; ++i)
-            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcB[i] + (int64_t)cb.slab * (BIL ? 2 * BK : BK)), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gas_ptr2)(srcB[i] + (int64_t)cb.slab * (BIL ? 2 * BK : BK)), (las_ptr2)(st + (i * NW + wave) * 1024), 16, 0, PAA_R2_B_AUX);
         if (advance(cb, NSTB) && cb.t < total) set_srcB(cb.t);
     };
     set_srcA(ca.t);
