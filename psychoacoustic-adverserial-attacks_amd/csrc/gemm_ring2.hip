@@ -132,16 +132,22 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     auto set_srcA = [&](int t) {
         const Tile c = decode(t);
         const int64_t aoff = c.z1 * d.a_s1 + c.z2 * d.a_s2;
+        // The per-lane row / chunk indices below are loop-invariant; left visible, the compiler keeps all GA of them live across the
+        // K loop, runs out of registers and RELOADS them from scratch right here — with an s_waitcnt vmcnt(0) that drains the whole
+        // operand pipeline once per tile.  Recomputing them from an opaque copy of the lane id costs a dozen ALU instructions per tile.
+        // (the lane id itself comes from v_mbcnt inside the statement: an opaque copy of `lane` would just move the spill to `lane`)
+        int lane_o;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
             if constexpr (AIL) {
-                const int rr = (i * NW + wave) * RPIA + lane / CPRA;      // row of the slot (128-byte rows: chunks 0-3 hi, 4-7 lo)
-                const int ch = (lane % CPRA) ^ ((rr / RBRA) & (CPRA - 1));
+                const int rr = (i * NW + wave) * RPIA + lane_o / CPRA;    // row of the slot (128-byte rows: chunks 0-3 hi, 4-7 lo)
+                const int ch = (lane_o % CPRA) ^ ((rr / RBRA) & (CPRA - 1));
                 srcA[i] = reinterpret_cast<const unsigned short*>(d.A_il) + 2 * aoff + (int64_t)min(c.m0 + rr, d.M - 1) * (2 * d.lda) + ch * 8;
             } else {
-                const int r = (i * NW + wave) * RPI + lane / CPR;         // row of the slot: hi rows, then lo rows
+                const int r = (i * NW + wave) * RPI + lane_o / CPR;       // row of the slot: hi rows, then lo rows
                 const int pl = r / BM, rr = r - pl * BM;
-                const int ch = (lane % CPR) ^ ((rr / RBR) & (CPR - 1));   // global chunk that lands in slot lane % CPR
+                const int ch = (lane_o % CPR) ^ ((rr / RBR) & (CPR - 1)); // global chunk that lands in slot lane % CPR
                 const unsigned short* A = reinterpret_cast<const unsigned short*>(pl ? d.A_lo : (const void*)d.A) + aoff;
                 srcA[i] = A + (int64_t)min(c.m0 + rr, d.M - 1) * d.lda + ch * 8;
             }
@@ -150,11 +156,13 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     auto set_srcB = [&](int t) {
         const Tile c = decode(t);
         const int64_t boff = c.z1 * d.b_s1 + c.z2 * d.b_s2;
+        int lane_o;                                            // as in set_srcA
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
-            const int r = (i * NW + wave) * RPIB + lane / CPRB;
+            const int r = (i * NW + wave) * RPIB + lane_o / CPRB;
             const int pl = BIL ? 0 : r / BN, p = r - pl * BN;
-            const int ch = (lane % CPRB) ^ ((p / RBRB) & (CPRB - 1));
+            const int ch = (lane_o % CPRB) ^ ((p / RBRB) & (CPRB - 1));
             const int nl = (p & ~63) + 8 * ((p & 31) >> 2) + 4 * ((p >> 5) & 1) + (p & 3);      // row permutation of the vector epilogue
             if constexpr (BIL) {
                 srcB[i] = reinterpret_cast<const unsigned short*>(d.B_il) + 2 * boff + (int64_t)min(c.n0 + nl, d.N - 1) * (2 * d.ldb) + ch * 8;
