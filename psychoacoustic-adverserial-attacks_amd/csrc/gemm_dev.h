@@ -198,10 +198,15 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
     }
     // residual = LayerNorm(stored input) (gemm.h, res_ln_stats): gain / bias of this lane's 8 columns
     const bool rln = d.res_ln_stats != nullptr && !gg && ex != nullptr;
+    // 256-row tiles (MI = 4: 128 accumulator registers per wave at a 256-register budget) cannot afford 16 registers for them across
+    // the row groups — held there, the compiler spilled and reloaded other epilogue state around every store burst, each reload behind
+    // an s_waitcnt vmcnt(0) that also waits for the stores.  They re-read the 8 columns' gain / bias per row group instead (cache hits;
+    // the post-LN residual products have N = 768 and run 192-row tiles, so this path is cold).
+    constexpr bool RLN_HELD = MI < 4;
     float lg[8], lb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { lg[k] = 1.f; lb[k] = 0.f; }
-    if (rln && col_ok) {
+    if (RLN_HELD && rln && col_ok) {
         const float4 g0 = *reinterpret_cast<const float4*>(d.res_ln_g + (unsigned)col), g1 = *reinterpret_cast<const float4*>(d.res_ln_g + (unsigned)col + 4u);
         const float4 b0 = *reinterpret_cast<const float4*>(d.res_ln_b + (unsigned)col), b1 = *reinterpret_cast<const float4*>(d.res_ln_b + (unsigned)col + 4u);
         lg[0] = g0.x; lg[1] = g0.y; lg[2] = g0.z; lg[3] = g0.w; lg[4] = g1.x; lg[5] = g1.y; lg[6] = g1.z; lg[7] = g1.w;
@@ -260,8 +265,18 @@ __device__ __forceinline__ void epilogue_vec(const paa_gemm_desc& d, f32x16 (&ac
                 e4[2] = __uint_as_float(xv[u][j].z); e4[3] = __uint_as_float(xv[u][j].w);
             }
             if (rln) {
+                if constexpr (RLN_HELD) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) e4[k] = (e4[k] - rst.x) * rst.y * lg[4 * j + k] + lb[4 * j + k];
+                    for (int k = 0; k < 4; ++k) e4[k] = (e4[k] - rst.x) * rst.y * lg[4 * j + k] + lb[4 * j + k];
+                } else {
+                    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (col_ok) {
+                        g4 = *reinterpret_cast<const float4*>(d.res_ln_g + (unsigned)col + 4u * j);
+                        b4 = *reinterpret_cast<const float4*>(d.res_ln_b + (unsigned)col + 4u * j);
+                    }
+                    e4[0] = (e4[0] - rst.x) * rst.y * g4.x + b4.x; e4[1] = (e4[1] - rst.x) * rst.y * g4.y + b4.y;
+                    e4[2] = (e4[2] - rst.x) * rst.y * g4.z + b4.z; e4[3] = (e4[3] - rst.x) * rst.y * g4.w + b4.w;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = x[k] * alpha + bv[4 * j + k];

@@ -52,6 +52,16 @@ typedef __attribute__((address_space(3))) void* las_ptr2;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt2() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Diagnostic build -DPAA_R2_STAMP (tools/gemm_stamps.py): where a K slab's cycles go, per wave of workgroup 0 — s_memtime around the
+// counted vmcnt wait and around the barrier of every slab, summed per tile.
+#if defined(PAA_R2_STAMP) && !defined(PAA_EXPERIMENTS)
+#error "PAA_R2_STAMP is a diagnostic build: add -DPAA_EXPERIMENTS"
+#endif
+#ifdef PAA_R2_STAMP
+__device__ long long g_r2_stamp[8 * 16 * 6];          // [wave][tile < 16][slabs, loop cycles, vmcnt wait, barrier wait, epilogue, first slab start]
+#define R2_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#endif
+
 // BIL (split mode): the B operand comes from paa_gemm_desc.B_il — hi and lo planes interleaved per 32-element K group — so a K slab
 // of a weight row is ONE 128-byte line; its slot has 128-byte rows (chunks 0-3 hi, 4-7 lo) with the XOR swizzle of the bf16 kernels.
 // AIL (split mode only): likewise the A operand from paa_gemm_desc.A_il — the activations' planes interleaved per 32-element K group by
@@ -227,8 +237,15 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
     constexpr int NM = NJ * (PREC ? 3 : 1);
     bf16x8 bh[NJ], bl[NJ], bhn[NJ], bln[NJ], ah, al, ahn, aln;
     bool have_first = false;                   // the coming slab's first fragments are already in the "next" registers
+#ifdef PAA_R2_STAMP
+    int st_tile = 0;
+#endif
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const Tile cur = decode(t);
+#ifdef PAA_R2_STAMP
+        long long st_vm = 0, st_bar = 0;
+        const long long st_t0 = R2_NOW();
+#endif
         f32x16 acc[MI][2];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -279,11 +296,21 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                         // last MFMA group of the slab (its fragments are in registers): certify the next slab FIRST and read its
                         // first fragments under these MFMAs, instead of paying an LDS round trip with all eight waves at the top
                         // of the next step.  (Not across a tile boundary: the fragments would stay live over the epilogue.)
+#ifdef PAA_R2_STAMP
+                        const long long s0 = R2_NOW();
+#endif
                         if (ahead) wait_vmcnt2<GA>(); else wait_vmcnt2<0>();
+#ifdef PAA_R2_STAMP
+                        const long long s1 = R2_NOW();
+#endif
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my last fragment reads of this slab have returned: its slots may be refilled
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
+#ifdef PAA_R2_STAMP
+                        const long long s2 = R2_NOW();
+                        st_vm += s1 - s0; st_bar += s2 - s1;
+#endif
                         const unsigned char* san = smA + sa_slot * ASZ + arow;
                         const unsigned char* sbn = smB + sb_slot * BSZ + brow;
 #pragma unroll
@@ -328,7 +355,17 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#ifdef PAA_R2_STAMP
+        const long long st_t1 = R2_NOW();
+#endif
         epilogue_vec<MI, true>(d, acc, cur.m0 + wr * (BM / WR), cur.n0 + wc * (BN / WC), cur.z1, cur.z2, lane);
+#ifdef PAA_R2_STAMP
+        if (blockIdx.x == 0 && lane == 0 && st_tile < 16) {
+            long long* o = g_r2_stamp + (wave * 16 + st_tile) * 6;
+            o[0] = nk; o[1] = st_t1 - st_t0; o[2] = st_vm; o[3] = st_bar; o[4] = R2_NOW() - st_t1; o[5] = st_t0;
+        }
+        ++st_tile;
+#endif
     }
 }
 
@@ -355,6 +392,15 @@ void launch_ring2(const GemmArgs& g, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef PAA_R2_STAMP
+}  // namespace paa
+extern "C" int paa_debug_r2_stamps(long long* host) {      // diagnostic builds: the stamps of the LAST ring2 launch's workgroup 0
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(paa::g_r2_stamp), sizeof(long long) * 8 * 16 * 6) == hipSuccess ? 0 : 1;
+}
+namespace paa {
+#endif
 
 // configuration ids continue gemm_ring.hip's: 20 / 21 = 256 x 256 split / bf16, 22 / 23 = 192 x 256 split / bf16
 void launch_ring2_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
