@@ -397,7 +397,9 @@ void launch_ring2(const GemmArgs& g, hipStream_t st) {
 }  // namespace paa
 extern "C" int paa_debug_r2_stamps(long long* host) {      // diagnostic builds: the stamps of the LAST ring2 launch's workgroup 0
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(paa::g_r2_stamp), sizeof(long long) * 8 * 16 * 6) == hipSuccess ? 0 : 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(paa::g_r2_stamp), sizeof(long long) * 8 * 16 * 6) != hipSuccess) return 1;
+    static long long zeros[8 * 16 * 6];                   // next shape starts from a clean table
+    return hipMemcpyToSymbol(HIP_SYMBOL(paa::g_r2_stamp), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
 }
 namespace paa {
 #endif

@@ -29,6 +29,8 @@ for (nm, M, N, K, lda, ep) in G.SHAPES:
     L.paa_gemm_config(0)
     for _ in range(3):
         ms = G.timeit(d, 3)
+    assert L.paa_debug_r2_stamps(buf) == 0            # (also clears the table)
+    G.timeit(d, 1)
     assert L.paa_debug_r2_stamps(buf) == 0
     s = np.array(buf, dtype=np.int64).reshape(8, 16, 6)
     tiles = int((s[0, :, 0] > 0).sum())
