@@ -44,6 +44,9 @@ namespace {
 #ifndef PAA_R2_A_AUX
 #define PAA_R2_A_AUX 0
 #endif
+#ifndef PAA_R2_PRIO_BALANCE
+#define PAA_R2_PRIO_BALANCE 1
+#endif
 #ifndef PAA_R2_B_AUX
 #define PAA_R2_B_AUX 0
 #endif
@@ -322,7 +325,20 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring2(GemmArgs g) {
                         if (PREC) aln = *reinterpret_cast<const bf16x8*>(san + offal[0]);
                         have_first = true;
                     }
+#if PAA_R2_PRIO_BALANCE
+                    // The two waves of a SIMD share its matrix pipe; at equal priority the older one wins every tie, runs ahead, finishes its
+                    // slab ~1700 cycles early and parks at the barrier while the younger one drags its last third alone at a third of the
+                    // issue rate (stamps, tools/gemm_stamps.py).  Priority that FALLS with progress through the slab lets whichever wave is
+                    // behind win the pipe: 3, 3, 2, 2, 1, 1, 0, 0 over the 8 MFMA groups of a 256-row slab.
+                    switch (3 - ((ks * MI + i) * 4) / (KS * MI)) {
+                        case 3: __builtin_amdgcn_s_setprio(3); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        default: __builtin_amdgcn_s_setprio(0); break;
+                    }
+#else
                     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         if (PREC) {
