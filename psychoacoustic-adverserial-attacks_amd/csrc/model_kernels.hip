@@ -1239,6 +1239,139 @@ __global__ __launch_bounds__(128 * NS) void k_ctc_rec_mw(const int32_t* __restri
     }
 }
 
+// The same with K states per lane and wave (long label sequences: 2 S + 1 up to 1024 = 16 states per lane needs 32 one-state waves,
+// more than a workgroup holds): 2 NS / K waves per clip, wave w of a direction owning the K consecutive slots w K .. w K + K - 1 of
+// every lane.  A step is K lse3 per wave; neighbours inside the wave's own slots come from its registers (the previous step's
+// values), the two beyond its range from the exchange buffer.  Same arithmetic per state and same row layout as k_ctc_rec /
+// k_ctc_rec_mw: bit-identical results.  At S = 450, T = 1499 (30 s clips) the one-wave-per-direction kernel evaluated 16 states per
+// lane one after the other: ~2 ms of a 73 ms step.
+template <int NS, int K, bool LDS_TAB>
+__global__ __launch_bounds__(128 * NS / K) void k_ctc_rec_mwk(const int32_t* __restrict__ labels, int T, int V, int S_max, int blank,
+                                                               float* __restrict__ nll_out, float* __restrict__ work, int64_t wpc) {
+    static_assert(K >= 2 && NS % K == 0 && NS / K >= 2 && 2 * NS / K <= 16, "K states per lane and wave, 4 .. 16 waves");
+    extern __shared__ __attribute__((aligned(16))) double smd[];
+    constexpr int NWD = NS / K, NT = 128 * NWD, ROW = 64 * NS;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool fwd = wave < NWD;
+    const int jw = fwd ? wave : wave - NWD;                     // slot group of this wave
+    const int SPmax = 2 * S_max + 1;
+    const CtcWork w = ctc_work(work + (size_t)b * wpc, T, V, ROW);
+    double* xch = smd + (LDS_TAB ? (size_t)T * V : 0);          // [2 directions][2 buffers][NS][64]
+    int* lab = reinterpret_cast<int*>(xch + 4 * ROW);           // [SPmax] extended labels
+    __shared__ int s_len;
+    int* raw = lab + SPmax;                                     // [S_max]
+    for (int s = tid; s < S_max; s += NT) raw[s] = labels[(size_t)b * S_max + s];
+    if (LDS_TAB) {
+        const int n2 = T * V / 2;
+        const double2* src = reinterpret_cast<const double2*>(w.lp);
+        double2* dst = reinterpret_cast<double2*>(smd);
+        for (int i = tid; i < n2; i += NT) dst[i] = src[i];
+        if (((T * V) & 1) && tid == 0) smd[T * V - 1] = w.lp[T * V - 1];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int k = 0;
+        lab[0] = blank;
+        for (int s = 0; s < S_max; ++s) {
+            const int v = raw[s];
+            if (v >= 0) { lab[2 * k + 1] = v; lab[2 * k + 2] = blank; ++k; }
+        }
+        s_len = k;
+    }
+    const double* tab = LDS_TAB ? smd : w.lp;
+    __syncthreads();
+    const int S = s_len, SP = 2 * S + 1;
+    int l[K], o0[K];
+    double skn[K], dead[K];
+    bool on[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int slot = jw * K + k, s = lane * NS + slot;
+        l[k] = s < SP ? lab[s] : blank;
+        bool skip;
+        if (fwd) skip = s < SP && s >= 2 && l[k] != blank && l[k] != lab[s - 2];
+        else skip = s + 2 < SP && lab[s + 2] != blank && lab[s + 2] != l[k];
+        skn[k] = skip ? 0.0 : CTC_NEG;
+        dead[k] = s < SP ? 0.0 : CTC_NEG;
+        on[k] = (fwd ? (s == 0 || s == 1) : (s == SP - 1 || s == SP - 2)) && s < SP;
+        o0[k] = slot * 64 + lane;
+        if (fwd) w.lab[o0[k]] = s < SP ? l[k] : -1;
+    }
+    double* rows = fwd ? w.arow : w.brow;
+    double* xd = xch + (fwd ? 0 : 2 * ROW);                     // this direction's two buffers
+    // the two neighbours beyond the wave's own slots: fwd slots jw K - 1, jw K - 2 (of lane - 1 below slot 0); bwd slots (jw + 1) K,
+    // (jw + 1) K + 1 (of lane + 1 past slot NS - 1)
+    int on_[3];
+    bool okn[3];
+#pragma unroll
+    for (int m = 1; m <= 2; ++m) {
+        int slot = fwd ? jw * K - m : (jw + 1) * K + m - 1, ln = lane;
+        if (slot < 0) { slot += NS; ln -= 1; }
+        if (slot >= NS) { slot -= NS; ln += 1; }
+        okn[m] = ln >= 0 && ln < 64;
+        on_[m] = slot * 64 + (okn[m] ? ln : 0);
+    }
+    const int t0 = fwd ? 0 : T - 1;
+    double em[K], a[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        em[k] = tab[(size_t)t0 * V + l[k]] + dead[k];
+        a[k] = on[k] ? em[k] : CTC_NEG;
+        rows[(size_t)t0 * ROW + o0[k]] = a[k];
+        xd[ROW + o0[k]] = a[k];                                 // step 1 reads buffer 1
+    }
+    if (T > 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) em[k] = tab[(size_t)(fwd ? 1 : T - 2) * V + l[k]] + dead[k];
+    }
+    for (int i = 1; i < T; ++i) {
+        const int t = fwd ? i : T - 1 - i;
+        double emn[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) emn[k] = 0.0;
+        if (i + 1 < T) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) emn[k] = tab[(size_t)(fwd ? i + 1 : T - 2 - i) * V + l[k]] + dead[k];       // next step's emissions fly under this step
+        }
+        __syncthreads();                                        // every wave's values of the previous step are in buffer i & 1
+        const double* in = xd + (i & 1) * ROW;
+        double nb[3];
+        nb[1] = okn[1] ? in[on_[1]] : CTC_NEG;
+        nb[2] = okn[2] ? in[on_[2]] : CTC_NEG;
+        double nw[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double x1, x2;
+            if (fwd) {
+                x1 = k >= 1 ? a[k >= 1 ? k - 1 : 0] : nb[1];
+                x2 = k >= 2 ? a[k >= 2 ? k - 2 : 0] : nb[2 - k];
+            } else {
+                x1 = k + 1 < K ? a[k + 1 < K ? k + 1 : 0] : nb[1];
+                x2 = k + 2 < K ? a[k + 2 < K ? k + 2 : 0] : nb[k + 3 - K];
+            }
+            nw[k] = ctc_lse3(a[k], x1, x2 + skn[k]) + em[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            a[k] = nw[k];
+            xd[((i + 1) & 1) * ROW + o0[k]] = a[k];
+            rows[(size_t)t * ROW + o0[k]] = a[k];
+            em[k] = emn[k];
+        }
+    }
+    __syncthreads();                                            // the last alpha row is in buffer T & 1
+    if (tid == 0) {   // log P = lse(alpha_{T-1}(S'-1), alpha_{T-1}(S'-2))
+        const double* fin = xch + (T & 1) * ROW;
+        const int sa = SP - 1, sb = SP - 2;
+        const double va = fin[(sa % NS) * 64 + sa / NS];
+        const double vb = SP >= 2 ? fin[(sb % NS) * 64 + sb / NS] : CTC_NEG;
+        const double nll = -ctc_lse3(va, vb, CTC_NEG);
+        *w.nll = nll;
+        nll_out[b] = nll < 1e29 ? (float)nll : INFINITY;
+    }
+}
+
 // gradient rows: one wave per frame (grid: frames / 4 x clips)
 template <int NS>
 __global__ __launch_bounds__(256) void k_ctc_grad(int T, int Tpad, int V, float gscale, float* __restrict__ dlogits, Bf dlb,
@@ -1300,6 +1433,24 @@ static paa_status launch_ctc_ws(const float* logits, const int32_t* labels, int 
         }
         if (ltab) hipLaunchKernelGGL((k_ctc_rec_mw<NS, true>), dim3(B), dim3(128 * NS), ldsm, st, labels, T, V, S_max, blank, nll, work, wpc);
         else hipLaunchKernelGGL((k_ctc_rec_mw<NS, false>), dim3(B), dim3(128 * NS), ldsm, st, labels, T, V, S_max, blank, nll, work, wpc);
+        PAA_LAUNCH_CHECK();
+        if (dlogits) {
+            hipLaunchKernelGGL((k_ctc_grad<NS>), dim3(cdiv(Tpad, 4), B), dim3(256), sizeof(unsigned) * 4 * V, st, T, Tpad, V, gscale, dlogits, dlb, work, wpc);
+            PAA_LAUNCH_CHECK();
+        }
+        return PAA_OK;
+    }
+    if constexpr (NS == 16) {                 // two states per lane and wave, sixteen waves (k_ctc_rec_mwk)
+        const size_t xch = sizeof(double) * 4 * 64 * NS;
+        const bool ltab = tab + xch + small <= 150 * 1024;
+        const size_t ldsm = xch + small + (ltab ? tab : 0);
+        static bool attr_mwk = false;
+        if (!attr_mwk) {
+            PAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctc_rec_mwk<NS, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            attr_mwk = true;
+        }
+        if (ltab) hipLaunchKernelGGL((k_ctc_rec_mwk<NS, 2, true>), dim3(B), dim3(128 * NS / 2), ldsm, st, labels, T, V, S_max, blank, nll, work, wpc);
+        else hipLaunchKernelGGL((k_ctc_rec_mwk<NS, 2, false>), dim3(B), dim3(128 * NS / 2), ldsm, st, labels, T, V, S_max, blank, nll, work, wpc);
         PAA_LAUNCH_CHECK();
         if (dlogits) {
             hipLaunchKernelGGL((k_ctc_grad<NS>), dim3(cdiv(Tpad, 4), B), dim3(256), sizeof(unsigned) * 4 * V, st, T, Tpad, V, gscale, dlogits, dlb, work, wpc);

@@ -404,10 +404,12 @@ def test_softmax_fwd_bwd():
 
 # label capacities: 2 S_max + 1 <= 1024 -> wave-synchronous log-domain kernels (1, 2, 6, 16 states per lane);
 # (700, 600): the log-domain kernel for larger capacities; (60, 30, [.., 40->infeasible]) is covered by lens > T below
-# (499, 100) and (499, 250): 4 and 8 states per lane — with 2 and 6 the shapes of the one-wave-per-state-slot recursion (k_ctc_rec_mw)
+# (499, 100) and (499, 250): 4 and 8 states per lane — with 2 and 6 the shapes of the one-wave-per-state-slot recursion (k_ctc_rec_mw);
+# (499, 499) and (1499, 450, the 30 s clips): 16 states per lane = sixteen waves of two states (k_ctc_rec_mwk)
 @pytest.mark.parametrize("T,S_max,lens", [(24, 6, [5, 6, 3, 0]), (499, 150, [150, 120, 1, 77]), (60, 30, [30, 29, 30, 2]),
                                           (80, 40, [40, 1, 33, 40]), (499, 499, [300, 150, 499, 250]), (700, 600, [600, 150, 20, 333]),
-                                          (499, 100, [100, 99, 2, 50]), (499, 250, [250, 130, 249, 0]), (1, 40, [1, 0, 1, 1])])
+                                          (499, 100, [100, 99, 2, 50]), (499, 250, [250, 130, 249, 0]), (1, 40, [1, 0, 1, 1]),
+                                          (1499, 450, [450, 301, 1, 449])])
 def test_ctc(T, S_max, lens):
     torch.manual_seed(2)
     B, V = len(lens), 32
