@@ -362,7 +362,7 @@ constexpr int C0_GCH = 2048;       // frames per workgroup of the Gram kernel
 constexpr int C0_GQ = 66;          // 55 lower-triangle products + 10 sums (+1 pad)
 __global__ __launch_bounds__(256) void k_conv0_gram(Conv0Args a, double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    __shared__ double red[256 / 64];
+    __shared__ double red[256 / 64][C0_GQ];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int t0 = chunk * C0_GCH;
     const int nt = min(C0_GCH, a.T - t0);
@@ -384,11 +384,21 @@ __global__ __launch_bounds__(256) void k_conv0_gram(Conv0Args a, double* __restr
 #pragma unroll
         for (int j = 0; j < 10; ++j) acc[55 + j] += xw[j];
     }
+    // 65 block sums: the wave sums first, ONE exchange through LDS, then the four waves' values in block_sum's own order (65 block_sum
+    // calls were 130 barriers in a row: 51 us for a kernel that moves 20 MB)
     double* out = part + ((size_t)b * gridDim.x + chunk) * C0_GQ;
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < 65; ++q) {
-        const double t = block_sum<double, 256>((double)acc[q], red);
-        if (threadIdx.x == 0) out[q] = t;
+        const double t = wave_sum((double)acc[q]);
+        if ((threadIdx.x & 63) == 0) red[wv][q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 65) {
+        double r = 0;
+#pragma unroll
+        for (int i = 0; i < 256 / 64; ++i) r += red[i][threadIdx.x];
+        out[threadIdx.x] = r;
     }
 }
 
