@@ -611,3 +611,45 @@ def test_spec_pk_primitives(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "transpose_hi: 0 wrong" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+
+
+@pytest.mark.parametrize("cfg,N", [(1, 768), (22, 768), (20, 512), (0, 768), (0, 1024)])
+def test_gemm_residual_layernorm_of_stored_input(cfg, N):
+    """gemm.h res_ln_stats: the residual the epilogue adds is LayerNorm(x) evaluated from the stored x and its (mean, rstd) rows.
+    The 192-row tiles hold the 8 columns' gain / bias in registers, the 256-row tiles re-read them per row group (gemm_dev.h,
+    RLN_HELD) — a path the model never takes (its post-LN residual products have N = 768), so it is forced here (cfg 20)."""
+    from paa_amd.model import bf16_to_f32, split_bf16
+    M, K = 2304, 256
+    rng = np.random.default_rng(11)
+    A, B = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(N, K)).astype(np.float32) * 0.1
+    x = rng.normal(size=(M, N)).astype(np.float32) * 2 + 0.3
+    g, b = rng.normal(size=N).astype(np.float32), rng.normal(size=N).astype(np.float32)
+    mean = x.astype(np.float64).mean(1)
+    rstd = 1.0 / np.sqrt(x.astype(np.float64).var(1) + 1e-5)
+    stats = np.stack([mean, rstd], 1).astype(np.float32)
+    ah, al = split_bf16(A.ravel()); bh, bl = split_bf16(B.ravel())
+    Ar = (bf16_to_f32(ah).astype(np.float64) + bf16_to_f32(al)).reshape(M, K)
+    Br = (bf16_to_f32(bh).astype(np.float64) + bf16_to_f32(bl)).reshape(N, K)
+    ref = Ar @ Br.T + ((x.astype(np.float64) - stats[:, :1].astype(np.float64)) * stats[:, 1:].astype(np.float64)) * g + b
+    t = {k: torch.from_numpy(v.view(np.int16)).cuda() for k, v in dict(ah=ah, al=al, bh=bh, bl=bl).items()}
+    xd, gd, bd, sd = dev(x.ravel()), dev(g), dev(b), dev(stats.ravel())
+    out = torch.zeros(M * N, device="cuda")
+    d = _lib.PaaGemmDesc()
+    d.a_kcontig = d.b_kcontig = 1
+    d.batch = d.batch2 = 1
+    d.alpha = 1.0
+    d.operand_bf16 = d.precision = 1
+    d.A, d.A_lo, d.B, d.B_lo = t["ah"].data_ptr(), t["al"].data_ptr(), t["bh"].data_ptr(), t["bl"].data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ld_res = M, N, K, K, K, N, N
+    d.C, d.residual = out.data_ptr(), xd.data_ptr()
+    d.res_ln_stats, d.res_ln_g, d.res_ln_b = sd.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    L = _lib.lib()
+    try:
+        L.paa_gemm_config(cfg)
+        _lib.check(L.paa_gemm(C.byref(d), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        L.paa_gemm_config(0)
+    e = rel_err(out.cpu().numpy().reshape(M, N), ref)
+    print(f"res_ln cfg {cfg} N {N}: rel err {e:.2e}")
+    assert e < 3e-5
