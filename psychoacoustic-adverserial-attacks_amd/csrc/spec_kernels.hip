@@ -4,16 +4,25 @@
 // _align_to  chain (training_utils/train.py:38-66, core/fourier_transforms.py:20-41, core/projections.py:68-159):
 //
 //  * ONE WAVE PER FRAME.  A real 1024-point frame is a 512-point complex FFT of z[m] = x[2m] + i x[2m+1] plus a split
-//    post-pass; 512 = 8 x 8 x 8, so the FFT is three radix-8 passes with 8 complex values per lane in registers, and
-//    the two transposes between passes go through a 5 KB per-wave LDS buffer with conflict-free layouts
-//    (rows of 72 / 10 complex) — no workgroup barrier inside a frame, twiddles and window in registers.
-//  * The per-bin projection runs on the post-pass registers (bin k and its mirror 512 - k live in one lane), feeds the
-//    inverse pre-pass directly, then three inverse radix-8 passes, window, and the windowed frame stays in LDS.
-//  * A workgroup of NW waves handles NW consecutive frames of one row and overlap-adds them in LDS: output hop-block j
-//    is the sum of frames j-3..j, so NW frames give NW - 3 complete blocks (the 3-frame halo is recomputed by the
-//    neighbouring workgroup); envelope division, the FM scale's partial sum, trimming of the reflect padding and the
-//    zero tail of _align_to happen on the way out.  Windowed frames never touch HBM (the round-1 kernels wrote and
-//    re-read 4 x L floats per row): algorithmic traffic is read p + write p.
+//    post-pass; 512 = 8 x 8 x 8, so the FFT is three radix-8 passes with 8 complex values per lane in registers.  The arithmetic
+//    is written as single packed-f32 instructions with operand modifiers (spec_pk.h: a butterfly is 26 instructions, a complex
+//    product 2, no moves, and every kernel rounds a frame the same way).  The exchange between the first two passes is an 8 x 8
+//    register / lane transpose in registers (v_permlane32_swap, v_permlane16_swap, masked DPP moves); the second goes through a
+//    5 KB per-wave LDS buffer with a conflict-free layout (rows of 10 complex) — no workgroup barrier inside a frame, twiddles
+//    and window in registers.
+//  * A lane owns bins lane + 64 j (its own registers after the forward transform) and their mirrors 512 - k, which sit in lane
+//    64 - lane, register 7 - j: the split post-pass and the inverse pre-pass pull them through the LDS crossbar (ds_bpermute),
+//    not through memory.  Lane 0 carries (DC, Nyquist) as its pair 0 and bin 256 as a ninth bin.  The per-bin projection runs on
+//    those registers and feeds the inverse pre-pass directly, then three inverse radix-8 passes, window, and the windowed frame
+//    stays in LDS.
+//  * Single rows / small batches (k_spec_fused): a workgroup of 8 waves handles 8 consecutive frames of one row and overlap-adds
+//    them in LDS: output hop-block j is the sum of frames j-3..j, so 8 frames give 5 complete blocks (the 3-frame halo is
+//    recomputed by the neighbouring workgroup).  Batches (k_spec_run): a workgroup of 12 waves WALKS a run of consecutive blocks,
+//    12 frames per iteration; the three frames the next blocks reach back to stay in LDS, twiddles are loaded once per run, the
+//    next frame's samples are requested before the iteration's LDS-only barrier, and wave w overlap-adds the block whose newest
+//    frame is its own.  Envelope division, the FM scale's partial sum, trimming of the reflect padding and the zero tail of
+//    _align_to happen on the way out.  Windowed frames never touch HBM: algorithmic traffic is read p + write p (measured
+//    1.04 x that on the batch).
 //  * FM norm (projections.py:83-133): the same launch leaves sqrt-free partial sums (one double per workgroup, only
 //    frames the workgroup OWNS are counted); the scale is a predicated factor applied by the copy-back / scale kernel.
 #include <stdlib.h>
